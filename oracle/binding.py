@@ -1,0 +1,212 @@
+"""ctypes binding of the CPU oracle (test infrastructure only).
+
+`load()` returns an `OracleApi`: the scene-construction mirror (raytracer_amd/mirror.py) bound to
+liboracle.so, plus the evaluation entry points the known-answer tests need (intersect, normal_at,
+color_at, shade_hit, ... and a full-frame render).  Only tests, the smoke check and the benchmark's
+CPU-baseline leg may import this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from raytracer_amd.mirror import Api, _arr, c_d, c_dp, c_i64
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(HERE, "liboracle.so")
+
+COUNTER_NAMES = [
+    "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "aabb_test", "sphere_test",
+    "plane_test", "cube_test", "cyl_test", "cone_test", "tri_test", "ray_xform", "shaded_hits",
+    "light_evals", "pattern_nodes", "inverses",
+]
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE])
+
+
+class OracleApi(Api):
+    def __init__(self, lib):
+        super().__init__(lib, "orc_")
+        L = lib
+        c_ip = C.POINTER(c_i64)
+        sig = {
+            "set_faithful": (None, [C.c_int]),
+            "mat_determinant": (c_d, [c_dp]),
+            "mat_cofactor": (c_d, [c_dp, C.c_int, C.c_int]),
+            "tuple_normalize": (None, [c_dp, c_dp]),
+            "tuple_magnitude": (c_d, [c_dp]),
+            "tuple_dot": (c_d, [c_dp, c_dp]),
+            "tuple_cross": (None, [c_dp, c_dp, c_dp]),
+            "tuple_reflect": (None, [c_dp, c_dp, c_dp]),
+            "shape_parent": (c_i64, [c_i64]),
+            "bbox_intersects": (C.c_int, [c_dp, c_dp, c_dp]),
+            "bbox_contains_point": (C.c_int, [c_dp, c_dp]),
+            "bbox_contains_box": (C.c_int, [c_dp, c_dp]),
+            "bbox_transform": (None, [c_dp, c_dp, c_dp]),
+            "bbox_split": (None, [c_dp, c_dp, c_dp]),
+            "intersect": (C.c_int, [c_i64, c_dp, c_dp, c_dp, c_ip, c_dp, C.c_int]),
+            "normal_at": (None, [c_i64, c_dp, c_d, c_d, c_dp]),
+            "local_normal_at": (None, [c_i64, c_dp, c_d, c_d, c_dp]),
+            "world_to_object": (None, [c_i64, c_dp, c_dp]),
+            "normal_to_world": (None, [c_i64, c_dp, c_dp]),
+            "pattern_at_shape": (None, [c_i64, c_i64, c_dp, c_dp]),
+            "pattern_at": (None, [c_i64, c_dp, c_dp]),
+            "perlin_noise": (c_d, [c_dp]),
+            "lighting": (None, [c_i64, c_i64, c_dp, c_dp, c_dp, c_dp, c_dp, C.c_int, c_dp]),
+            "ray_for_pixel": (None, [c_i64, c_i64, c_i64, c_dp, c_dp]),
+            "world_intersect": (C.c_int, [c_i64, c_dp, c_dp, c_dp, c_ip, C.c_int]),
+            "prepare": (C.c_int, [c_i64, c_dp, c_dp, c_dp]),
+            "comps_eval": (C.c_int, [c_i64, c_dp, c_dp, c_dp, c_ip, C.c_int, C.c_int, C.c_int,
+                                     C.c_int, c_dp]),
+            "color_at": (None, [c_i64, c_dp, c_dp, C.c_int, c_dp]),
+            "color_at_batch": (None, [c_i64, c_i64, c_dp, c_dp, C.c_int, c_dp]),
+            "is_shadowed": (C.c_int, [c_i64, c_dp, c_dp, c_dp]),
+            "render_rows": (None, [c_i64, c_i64, C.c_int, c_i64, c_i64, C.c_int, c_dp,
+                                   C.POINTER(C.c_uint64)]),
+            "num_counters": (C.c_int, []),
+            "clamp_u8": (C.c_int, [c_d]),
+            "to_ppm": (c_i64, [c_dp, c_i64, c_i64]),
+            "ppm_copy": (None, [C.c_char_p]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(L, "orc_" + name)
+            fn.restype = res
+            fn.argtypes = args
+
+    # ---- evaluation helpers -------------------------------------------------------------------
+    def set_faithful(self, on):
+        self._f("set_faithful")(int(bool(on)))
+
+    def intersect(self, shape, ray, cap=64):
+        """Shape::intersect -> list of (t, object handle, u, v)."""
+        ts = (c_d * cap)()
+        objs = (c_i64 * cap)()
+        uv = (c_d * (2 * cap))()
+        n = self._f("intersect")(shape.h, _arr(ray.origin), _arr(ray.direction), ts, objs, uv, cap)
+        return [(ts[i], objs[i], uv[2 * i], uv[2 * i + 1]) for i in range(min(n, cap))]
+
+    def normal_at(self, shape, p, u=0.0, v=0.0):
+        out = (c_d * 4)()
+        self._f("normal_at")(shape.h, _arr(p), u, v, out)
+        return tuple(out)
+
+    def local_normal_at(self, shape, p, u=0.0, v=0.0):
+        out = (c_d * 4)()
+        self._f("local_normal_at")(shape.h, _arr(p), u, v, out)
+        return tuple(out)
+
+    def world_to_object(self, shape, p):
+        out = (c_d * 4)()
+        self._f("world_to_object")(shape.h, _arr(p), out)
+        return tuple(out)
+
+    def normal_to_world(self, shape, n):
+        out = (c_d * 4)()
+        self._f("normal_to_world")(shape.h, _arr(n), out)
+        return tuple(out)
+
+    def pattern_at_shape(self, pattern, shape, p):
+        out = (c_d * 3)()
+        self._f("pattern_at_shape")(pattern.h, shape.h, _arr(p), out)
+        return tuple(out)
+
+    def pattern_at(self, pattern, p):
+        out = (c_d * 3)()
+        self._f("pattern_at")(pattern.h, _arr(p), out)
+        return tuple(out)
+
+    def lighting(self, material, shape, light, p, eyev, normalv, in_shadow):
+        out = (c_d * 3)()
+        self._f("lighting")(material.h, shape.h, _arr(light.position[:3]), _arr(light.intensity),
+                            _arr(p), _arr(eyev), _arr(normalv), int(in_shadow), out)
+        return tuple(out)
+
+    def ray_for_pixel(self, camera, px, py):
+        o = (c_d * 4)()
+        d = (c_d * 4)()
+        self._f("ray_for_pixel")(camera.h, px, py, o, d)
+        return self.Ray(tuple(o), tuple(d))
+
+    def intersect_world(self, world, ray, cap=256):
+        ts = (c_d * cap)()
+        objs = (c_i64 * cap)()
+        n = self._f("world_intersect")(world.h, _arr(ray.origin), _arr(ray.direction), ts, objs, cap)
+        return [(ts[i], objs[i]) for i in range(min(n, cap))]
+
+    def prepare(self, world, ray):
+        """prepare_computations for the ray's hit; None when nothing is hit."""
+        out = (c_d * 30)()
+        if not self._f("prepare")(world.h, _arr(ray.origin), _arr(ray.direction), out):
+            return None
+        o = list(out)
+        return dict(t=o[0], point=tuple(o[1:5]), over_point=tuple(o[5:9]), under_point=tuple(o[9:13]),
+                    eyev=tuple(o[13:17]), normalv=tuple(o[17:21]), reflectv=tuple(o[21:25]), n1=o[25],
+                    n2=o[26], inside=bool(o[27]), object=int(o[28]), schlick=o[29])
+
+    def comps_eval(self, world, ray, xs, hit_index, which, remaining=5):
+        """prepare_computations(hit_index, ray, xs) followed by shade_hit (0), reflected_color (1),
+        refracted_color (2) or (schlick, n1, n2) (3).  xs: list of (t, shape)."""
+        ts = _arr([t for t, _ in xs])
+        objs = (c_i64 * len(xs))(*[s.h for _, s in xs])
+        out = (c_d * 3)()
+        rc = self._f("comps_eval")(world.h, _arr(ray.origin), _arr(ray.direction), ts, objs, len(xs),
+                                   hit_index, which, remaining, out)
+        assert rc == 0
+        return tuple(out)
+
+    def color_at(self, world, ray, remaining=5):
+        out = (c_d * 3)()
+        self._f("color_at")(world.h, _arr(ray.origin), _arr(ray.direction), remaining, out)
+        return tuple(out)
+
+    def color_at_batch(self, world, origins, directions, remaining=5):
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        out = np.empty_like(o)
+        self._f("color_at_batch")(world.h, o.shape[0], o.ctypes.data_as(c_dp), d.ctypes.data_as(c_dp),
+                                  remaining, out.ctypes.data_as(c_dp))
+        return out
+
+    def is_shadowed(self, world, p, light):
+        return bool(self._f("is_shadowed")(world.h, _arr(p), _arr(light.position[:3]),
+                                           _arr(light.intensity)))
+
+    def render(self, world, camera, remaining=5, threads=None, rows=None, counters=False):
+        """render (src/lib.rs:77-133) -> float64 array (H, W, 3).  rows=(r0, r1) limits the work to
+        those rows (the rest of the frame stays zero)."""
+        W, H = camera.width(), camera.height()
+        threads = threads or min(os.cpu_count() or 1, 16)
+        r0, r1 = rows if rows else (0, H)
+        img = np.zeros((H, W, 3), dtype=np.float64)
+        cnt = (C.c_uint64 * self._f("num_counters")())()
+        self._f("render_rows")(world.h, camera.h, remaining, r0, r1, threads, img.ctypes.data_as(c_dp),
+                               cnt)
+        if counters:
+            return img, dict(zip(COUNTER_NAMES, [int(v) for v in cnt]))
+        return img
+
+    def clamp(self, v):
+        return self._f("clamp_u8")(float(v))
+
+    def to_ppm(self, img):
+        img = np.ascontiguousarray(img, dtype=np.float64)
+        h, w = img.shape[:2]
+        n = self._f("to_ppm")(img.ctypes.data_as(c_dp), w, h)
+        buf = C.create_string_buffer(n)
+        self._f("ppm_copy")(buf)
+        return buf.raw[:n]
+
+
+_API = None
+
+
+def load():
+    global _API
+    if _API is None:
+        if not os.path.exists(LIB):
+            build()
+        _API = OracleApi(C.CDLL(LIB))
+    return _API

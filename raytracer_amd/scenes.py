@@ -1,0 +1,185 @@
+"""Scene definitions for the measured configurations, written against the mirror interface.
+
+Every function takes an `Api` (see mirror.py) so that the same description can be built on the
+host library (for the HIP path) and on the test oracle.
+"""
+import math
+import os
+
+
+def build_world(api):
+    """The default scene of the reference's binary (src/lib.rs:135-323): a white ambient-only
+    backdrop plane and one group of a glass sphere plus seventeen cubes, `divide(1)`, two lights."""
+    M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+
+    def matte(color):
+        return Phong(Solid(color), 0.1, 0.7, 0.0, 200.0, 0.1, 0.0, 1.0)
+
+    white = matte(Color.white())
+    blue = matte(Color(0.537, 0.831, 0.914))
+    red = matte(Color(0.941, 0.322, 0.388))
+    purple = matte(Color(0.373, 0.404, 0.550))
+
+    standard = M.scaling(0.5, 0.5, 0.5) * M.translation(1.0, -1.0, 1.0)
+    large = M.scaling(3.5, 3.5, 3.5) * standard
+    medium = M.scaling(3.0, 3.0, 3.0) * standard
+    small = M.scaling(2.0, 2.0, 2.0) * standard
+
+    plane = api.Plane(
+        M.translation(0.0, 0.0, 500.0) * M.rotation_x(math.pi / 2.0),
+        Phong(Solid(Color.white()), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0),
+        True,
+    )
+
+    group = api.Group()
+    glass = Phong(Solid(Color(0.373, 0.404, 0.550)), 0.0, 0.2, 1.0, 200.0, 0.7, 0.7, 1.5)
+    cubes = [
+        ((4.0, 0.0, 0.0), medium, white),
+        ((8.5, 1.5, -0.5), large, blue),
+        ((0.0, 0.0, 4.0), large, red),
+        ((4.0, 0.0, 4.0), small, white),
+        ((7.5, 0.5, 4.0), medium, purple),
+        ((-0.25, 0.25, 8.0), medium, white),
+        ((4.0, 1.0, 7.5), large, blue),
+        ((10.0, 2.0, 7.5), medium, red),
+        ((8.0, 2.0, 12.0), small, white),
+        ((20.0, 1.0, 9.0), small, white),
+        ((-0.5, -5.0, 0.25), large, blue),
+        ((4.0, -4.0, 0.0), large, red),
+        ((8.5, -4.0, 0.0), large, white),
+        ((0.0, -4.0, 4.0), large, white),
+        ((-0.5, -4.5, 8.0), large, purple),
+        ((0.0, -8.0, 4.0), large, white),
+        ((-0.5, 8.5, 8.0), large, white),
+    ]
+    children = [api.Sphere(large, glass, True)]
+    for (tx, ty, tz), size, mat in cubes:
+        children.append(api.Cube(M.translation(tx, ty, tz) * size, mat, True))
+    group.add_children(children)
+    group.divide(1)
+
+    lights = [
+        api.PointLight(api.point(50.0, 100.0, -50.0), Color(1.0, 1.0, 1.0)),
+        api.PointLight(api.point(-400.0, 50.0, -10.0), Color(0.2, 0.2, 0.2)),
+    ]
+    return api.World([plane, group], lights)
+
+
+def default_camera(api, width, height):
+    """The camera `run` builds (src/lib.rs:59-68).  Note the argument order: the reference passes
+    (height, width) as (hsize, vsize), and the canvas is camera.width() x camera.height() =
+    vsize x hsize, so the image is `width` pixels wide."""
+    M = api.Matrix
+    return api.Camera(
+        height,
+        width,
+        0.785,
+        M.view_transform(api.point(-6.0, 6.0, -10.0), api.point(6.0, 0.0, 6.0),
+                         api.vector(-0.45, 1.0, 0.0)),
+    )
+
+
+def glass_world(api):
+    """A reflective + refractive scene that exercises every pattern and the quadrics: glass sphere
+    with an air bubble, mirror sphere with a ring pattern, Perlin-perturbed gradient, blended
+    pattern, closed cylinder and cone, checkered reflective floor.  Build-defined (the reference
+    ships no such scene); its oracle is the CPU restatement."""
+    M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+    floor = api.Plane(
+        M.identity(),
+        Phong(api.Checker(Solid(Color.white()), Solid(Color(0.15, 0.15, 0.15)), M.scaling(1, 1, 1)),
+              0.1, 0.9, 0.0, 200.0, 0.3, 0.0, 1.0),
+        True,
+    )
+    wall = api.Plane(
+        M.translation(0.0, 0.0, 10.0) * M.rotation_x(math.pi / 2.0),
+        Phong(api.Striped(Solid(Color(0.9, 0.3, 0.3)), Solid(Color(0.3, 0.3, 0.9)),
+                          M.scaling(0.5, 0.5, 0.5)),
+              1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0),
+        True,
+    )
+    glass = api.Sphere(
+        M.translation(0.0, 1.0, 0.0),
+        Phong(Solid(Color(0.05, 0.05, 0.05)), 0.0, 0.1, 1.0, 300.0, 0.9, 0.9, 1.5),
+        True,
+    )
+    bubble = api.Sphere(
+        M.translation(0.0, 1.0, 0.0) * M.scaling(0.5, 0.5, 0.5),
+        Phong(Solid(Color.white()), 0.0, 0.0, 0.0, 200.0, 0.0, 1.0, 1.0),
+        True,
+    )
+    mirror = api.Sphere(
+        M.translation(2.5, 1.0, 1.5),
+        Phong(api.Ring(Solid(Color(0.8, 0.8, 0.2)), Solid(Color(0.2, 0.6, 0.2)),
+                       M.scaling(0.25, 0.25, 0.25)),
+              0.1, 0.6, 0.9, 200.0, 0.8, 0.0, 1.0),
+        True,
+    )
+    noisy = api.Sphere(
+        M.translation(-2.5, 1.0, 1.5),
+        Phong(api.Perturbed(api.Gradient(Solid(Color.red()), Solid(Color.blue()),
+                                         M.translation(-1.0, 0.0, 0.0) * M.scaling(2, 2, 2)),
+                            0.2, M.identity()),
+              0.1, 0.8, 0.3, 100.0, 0.1, 0.0, 1.0),
+        True,
+    )
+    blend = api.Sphere(
+        M.translation(-1.0, 0.4, -2.0) * M.scaling(0.4, 0.4, 0.4),
+        Phong(api.Blended(api.Striped(), api.Checker(), M.identity()),
+              0.1, 0.8, 0.3, 100.0, 0.0, 0.0, 1.0),
+        True,
+    )
+    cyl = api.Cylinder(M.translation(1.5, 0.0, -2.0), api.Phong.default(), True, 0.0, 1.0, True)
+    cone = api.Cone(M.translation(3.5, 1.0, -1.0), api.Phong.default(), True, -1.0, 0.0, True)
+    lights = [
+        api.PointLight(api.point(-10.0, 10.0, -10.0), Color.white()),
+        api.PointLight(api.point(5.0, 8.0, -6.0), Color(0.3, 0.3, 0.3)),
+    ]
+    return api.World([floor, wall, glass, bubble, mirror, noisy, blend, cyl, cone], lights)
+
+
+def glass_camera(api, width, height):
+    M = api.Matrix
+    return api.Camera(height, width, math.pi / 3.0,
+                      M.view_transform(api.point(0.0, 2.5, -8.0), api.point(0.0, 1.0, 0.0),
+                                       api.vector(0.0, 1.0, 0.0)))
+
+
+OBJ_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden",
+                       "obj")
+
+
+def mesh_world(api, variant="teapot", obj_dir=OBJ_DIR):
+    """An OBJ mesh (the reference's tests/obj_files fixtures) parsed like
+    src/scene/obj_file_parser.rs does, grouped, `divide(1)` (as src/lib.rs:308 does for its group),
+    over a floor plane with one light.  Variants: teapot (flat triangles), smooth_teapot (smooth
+    triangles, Z-up so it is rotated and scaled), dragon (smooth triangles)."""
+    M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+    mat = Phong(Solid(Color(0.8, 0.33, 0.2)), 0.1, 0.7, 0.3, 200.0, 0.0, 0.0, 1.0)
+    if variant == "smooth_teapot":
+        t = M.rotation_x(-math.pi / 2.0) * M.scaling(0.2, 0.2, 0.2)
+    else:
+        t = M.identity()
+    parser = api.ObjFileParser.parse_obj_file(os.path.join(obj_dir, variant + ".obj"), M.identity(),
+                                              mat, True)
+    group = parser.obj_to_group(t)
+    group.divide(1)
+    floor = api.Plane(M.translation(0.0, -0.2, 0.0), Phong.default(), True)
+    lights = [api.PointLight(api.point(-10.0, 10.0, -10.0), Color.white())]
+    return api.World([floor, group], lights)
+
+
+def mesh_camera(api, width, height):
+    M = api.Matrix
+    return api.Camera(height, width, math.pi / 3.0,
+                      M.view_transform(api.point(0.0, 3.0, -9.0), api.point(0.0, 1.5, 0.0),
+                                       api.vector(0.0, 1.0, 0.0)))
+
+
+WORKLOADS = {
+    "default": (build_world, default_camera),
+    "glass": (glass_world, glass_camera),
+    "teapot": (lambda api: mesh_world(api, "teapot"), mesh_camera),
+    "smooth_teapot": (lambda api: mesh_world(api, "smooth_teapot"), mesh_camera),
+    "dragon": (lambda api: mesh_world(api, "dragon"), mesh_camera),
+}
