@@ -1,0 +1,170 @@
+/* C ABI of the MI355X render path (librt_amd.so).
+ *
+ * This is the boundary a host program binds to replace the reference's CPU render loop
+ *   pub fn render(world: Arc<World>, camera: Arc<Camera>) -> Canvas      (src/lib.rs:77-133)
+ * and the recursive shading entry point under it
+ *   World::color_at(&self, ray: &Ray, remaining: usize) -> Color          (src/scene/world.rs:198-212).
+ * The host flattens its scene graph into the plain tables below (one depth-first pre-order node
+ * array plus side tables), hands them over once, and then renders any number of frames.
+ *
+ * Conventions: every function returns 0 on success and a negative rt_status on failure, never
+ * throws or aborts; rt_last_error() gives a thread-local message.  All pointers in rt_scene_desc
+ * are host pointers that the library copies during rt_scene_create; the caller keeps ownership.
+ * A scene handle may be used from one thread at a time.  All arithmetic on the device is IEEE f64
+ * in the reference's evaluation order with no fused multiply-add contraction.
+ */
+#ifndef RT_ABI_H
+#define RT_ABI_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = -1, /* malformed table, null pointer, index out of range */
+    RT_ERR_HIP = -2,     /* a HIP runtime call failed */
+    RT_ERR_LIMIT = -3,   /* scene exceeds a documented limit (lights, nesting, depth) */
+    RT_ERR_NO_DEVICE = -4
+} rt_status;
+
+/* Limits checked by rt_scene_create / rt_render*. */
+#define RT_MAX_LIGHTS 4        /* point lights per scene */
+#define RT_MAX_DEPTH 5         /* `remaining` of the first ray; the reference uses 5 (src/lib.rs:21) */
+#define RT_MAX_XFORM_NEST 4    /* nested groups with a non-identity transform */
+#define RT_MAX_PATTERN_NEST 4  /* nested gradient/blended patterns */
+#define RT_TILE 8              /* a wavefront renders an 8x8 pixel tile */
+
+/* Node kinds: the shapes of src/geometry/{group,sphere,plane,cube,cylinder,cone,triangle,
+ * smooth_triangle}.rs. */
+enum { RT_GROUP = 0, RT_SPHERE, RT_PLANE, RT_CUBE, RT_CYLINDER, RT_CONE, RT_TRIANGLE, RT_SMOOTH_TRIANGLE };
+enum { RT_NODE_CASTS_SHADOW = 1, RT_NODE_CLOSED = 2 };
+
+/* One scene-graph node.  Nodes are stored in depth-first pre-order, children in the order the
+ * reference keeps them in Group::children (src/geometry/group.rs:19), top-level objects in
+ * World::objects order (src/scene/world.rs:16).  That order is what breaks ties between equal
+ * intersection times, because the reference's sorts are stable. */
+typedef struct rt_node {
+    int32_t type;     /* RT_GROUP ... RT_SMOOTH_TRIANGLE */
+    int32_t flags;    /* RT_NODE_* */
+    int32_t parent;   /* enclosing group, -1 for a World object */
+    int32_t skip;     /* first node after this node's subtree (== index + 1 for a leaf) */
+    int32_t material; /* leaves: index into materials; groups: -1 */
+    int32_t xform;    /* index into xforms, or -1 when the node's transform is the identity */
+    int32_t data;     /* group: aabbs index; cylinder/cone: ranges index; triangles: tris index; else -1 */
+    int32_t ctx;      /* nearest enclosing group whose transform is not the identity, or -1 */
+} rt_node;
+
+/* Inverse of a node transform, computed on the host by the reference's cofactor algorithm
+ * (src/matrices/matrix.rs:201-226).  inv holds rows 0..2 of the 4x4 inverse (row 3 is exactly
+ * 0 0 0 1 for affine transforms); inv_t holds the upper-left 3x3 of its transpose, row-major. */
+typedef struct rt_xform {
+    double inv[12];
+    double inv_t[9];
+    double reserved[3];
+} rt_xform;
+
+typedef struct rt_aabb { double min[3]; double max[3]; } rt_aabb;   /* Group::bounds, group.rs:196-208 */
+typedef struct rt_range { double minimum; double maximum; } rt_range; /* cylinder.rs:22-23, cone.rs:22-23 */
+typedef struct rt_tri { double p1[3]; double e1[3]; double e2[3]; } rt_tri; /* triangle.rs:23-28 */
+/* Flat triangle: n1 is the precomputed face normal (triangle.rs:48), n2/n3 unused.
+ * Smooth triangle: the three vertex normals (smooth_triangle.rs:28-30). */
+typedef struct rt_tri_normals { double n1[3]; double n2[3]; double n3[3]; } rt_tri_normals;
+
+/* Phong material (src/materials/phong.rs:10-19). */
+typedef struct rt_material {
+    double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    int32_t pattern; /* root of the pattern tree, index into patterns */
+    int32_t reserved;
+} rt_material;
+
+/* Pattern kinds: src/patterns/{solid,striped,gradient,ring,checker,blended,perturbed,test_pattern}.rs */
+enum { RT_PAT_SOLID = 0, RT_PAT_STRIPED, RT_PAT_GRADIENT, RT_PAT_RING, RT_PAT_CHECKER, RT_PAT_BLENDED,
+       RT_PAT_PERTURBED, RT_PAT_TEST };
+typedef struct rt_pattern {
+    int32_t type;
+    int32_t a;     /* former / delegate, index into patterns, -1 if none */
+    int32_t b;     /* latter, -1 if none */
+    int32_t xform; /* index into pattern_xforms (12 doubles each, rows 0..2 of the inverse), -1 = identity */
+    double color[3]; /* solid */
+    double scale;    /* perturbed */
+} rt_pattern;
+
+typedef struct rt_light { double position[3]; double intensity[3]; } rt_light; /* point_light.rs:9-19 */
+
+typedef struct rt_scene_desc {
+    int32_t n_nodes;          const rt_node* nodes;
+    int32_t n_xforms;         const rt_xform* xforms;
+    int32_t n_aabbs;          const rt_aabb* aabbs;
+    int32_t n_ranges;         const rt_range* ranges;
+    int32_t n_tris;           const rt_tri* tris;  const rt_tri_normals* tri_normals;
+    int32_t n_materials;      const rt_material* materials;
+    int32_t n_patterns;       const rt_pattern* patterns;
+    int32_t n_pattern_xforms; const double* pattern_xforms;
+    int32_t n_lights;         const rt_light* lights;
+} rt_scene_desc;
+
+/* Camera block: what Camera::new derives (src/scene/camera.rs:17-43) plus rows 0..2 of the
+ * inverse view transform.  width/height are the canvas size, i.e. Camera::width()/height()
+ * (camera.rs:68-74). */
+typedef struct rt_camera {
+    int32_t width, height;
+    double half_width, half_height, pixel_size;
+    double inv[12];
+} rt_camera;
+
+/* The image is split into row tiles of RT_TILE rows; tile t belongs to rank t % world_size
+ * (cyclic, like the reference's cyclic pixel partition, src/lib.rs:94-111).  A rank's rows are
+ * stored compactly: its k-th tile occupies rows [k*RT_TILE, (k+1)*RT_TILE) of its buffer. */
+typedef struct rt_params {
+    int32_t max_depth;  /* `remaining` for primary rays, 0..RT_MAX_DEPTH */
+    int32_t rank;       /* 0 <= rank < world_size */
+    int32_t world_size; /* >= 1 */
+    int32_t reserved;
+} rt_params;
+
+typedef struct rt_stats {
+    uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract; /* intersect_world equivalents */
+    float kernel_ms; /* device time of the render kernel (HIP events on its stream) */
+    float reserved;
+} rt_stats;
+
+typedef struct rt_scene rt_scene; /* opaque; owns the device copies of the tables */
+
+int rt_device_count(void);
+/* Copies the tables to `device` (a HIP device ordinal) after validating them. */
+int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
+void rt_scene_destroy(rt_scene* scene);
+
+/* Rows of the frame that `params->rank` renders (the compact buffer height). */
+int64_t rt_local_rows(int32_t height, const rt_params* params);
+/* Frame row stored at compact row `local_row` of `params->rank`. */
+int64_t rt_global_row(int64_t local_row, const rt_params* params);
+
+/* Replaces render (src/lib.rs:77-133) for this rank's rows.  d_rgb is DEVICE memory holding
+ * rt_local_rows * width * 3 doubles, pixel (x, local_row) at (local_row*width + x)*3.  The launch
+ * is asynchronous on `hip_stream` (a hipStream_t, may be NULL for the default stream). */
+int rt_render_device(rt_scene* scene, const rt_camera* camera, const rt_params* params,
+                     double* d_rgb, void* hip_stream);
+/* Same, but synchronous into HOST memory; fills stats when not NULL. */
+int rt_render(rt_scene* scene, const rt_camera* camera, const rt_params* params, double* rgb_out,
+              rt_stats* stats);
+/* Replaces World::color_at (src/scene/world.rs:198-212) for n rays given as packed xyz origins
+ * and directions in host memory; writes n*3 doubles to host memory. */
+int rt_color_at(rt_scene* scene, int64_t n, const double* origins, const double* directions,
+                int32_t remaining, double* rgb_out, rt_stats* stats);
+
+/* After the stream has been synchronised: device times (ms) of the most recent launches on this
+ * scene, oldest first, at most `cap`; returns how many were written. */
+int rt_scene_launch_times(rt_scene* scene, float* ms, int cap);
+/* Ray counters of the most recent launch (synchronises the launch's stream). */
+int rt_scene_ray_counts(rt_scene* scene, rt_stats* stats);
+
+const char* rt_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_ABI_H */

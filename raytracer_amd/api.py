@@ -1,0 +1,149 @@
+"""The shipped host interface: scene construction (mirror.Api bound to librt_host.so) plus `render`
+and `color_at`, which run on the GPU through the C ABI.  There is no CPU fallback: without the built
+libraries or without a GPU these calls raise."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+from .mirror import Api, c_d, c_dp, c_i64
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HOST_LIB = os.path.join(HERE, "host", "librt_host.so")
+
+
+class HostApi(Api):
+    def __init__(self):
+        if not os.path.exists(HOST_LIB):
+            raise RuntimeError("librt_host.so is not built: run __graft_entry__.build()")
+        self.abi = abi.load()  # librt_amd.so first (RTLD_GLOBAL), the host library links against it
+        lib = C.CDLL(HOST_LIB)
+        super().__init__(lib, "rth_")
+        P = C.POINTER
+        sig = {
+            "last_error": (C.c_char_p, []),
+            "camera_block": (C.c_int, [c_i64, P(abi.rt_camera)]),
+            "flatten": (C.c_int, [c_i64, P(C.c_int32)]),
+            "flat_nodes": (C.c_int, [c_i64, P(abi.rt_node)]),
+            "flat_aabbs": (C.c_int, [c_i64, P(abi.rt_aabb)]),
+            "flat_xforms": (C.c_int, [c_i64, P(abi.rt_xform)]),
+            "scene_desc": (C.c_int, [c_i64, P(abi.rt_scene_desc)]),
+            "world_scene": (C.c_int, [c_i64, C.c_int, P(C.c_void_p)]),
+            "render": (C.c_int, [c_i64, c_i64, C.c_int, P(abi.rt_params), c_dp, P(abi.rt_stats)]),
+            "render_device": (C.c_int, [c_i64, c_i64, C.c_int, P(abi.rt_params), C.c_void_p, C.c_void_p]),
+            "color_at": (C.c_int, [c_i64, C.c_int, c_i64, c_dp, c_dp, C.c_int, c_dp, P(abi.rt_stats)]),
+            "clamp_u8": (C.c_int, [c_d]),
+            "to_ppm": (c_i64, [c_dp, c_i64, c_i64]),
+            "ppm_copy": (None, [C.c_char_p]),
+        }
+        for name, (res, args) in sig.items():
+            fn = getattr(lib, "rth_" + name)
+            fn.restype = res
+            fn.argtypes = args
+
+    def _check(self, rc):
+        if rc != 0:
+            raise abi.RtError(rc, (self._f("last_error")() or b"").decode())
+
+    # ---- flatten inspection -------------------------------------------------------------------
+    def flatten(self, world):
+        """Flattens the world; returns the table sizes."""
+        counts = (C.c_int32 * 9)()
+        self._check(self._f("flatten")(world.h, counts))
+        keys = ["nodes", "xforms", "aabbs", "ranges", "tris", "materials", "patterns", "pattern_xforms",
+                "lights"]
+        return dict(zip(keys, [int(c) for c in counts]))
+
+    def flat_nodes(self, world):
+        n = self.flatten(world)["nodes"]
+        out = (abi.rt_node * max(n, 1))()
+        self._check(self._f("flat_nodes")(world.h, out))
+        return [out[i] for i in range(n)]
+
+    def flat_aabbs(self, world):
+        n = self.flatten(world)["aabbs"]
+        out = (abi.rt_aabb * max(n, 1))()
+        self._check(self._f("flat_aabbs")(world.h, out))
+        return [(tuple(out[i].min), tuple(out[i].max)) for i in range(n)]
+
+    def scene_desc(self, world):
+        d = abi.rt_scene_desc()
+        self._check(self._f("scene_desc")(world.h, C.byref(d)))
+        return d
+
+    def camera_block(self, camera):
+        cam = abi.rt_camera()
+        self._check(self._f("camera_block")(camera.h, C.byref(cam)))
+        return cam
+
+    def scene_handle(self, world, device=0):
+        h = C.c_void_p()
+        self._check(self._f("world_scene")(world.h, device, C.byref(h)))
+        return h
+
+    # ---- the render path ------------------------------------------------------------------------
+    def render(self, world, camera, max_depth=5, device=0, rank=0, world_size=1, stats=False):
+        """render(world, camera) (src/lib.rs:77-133) on the GPU -> float64 array (rows, W, 3).
+        With world_size > 1 only this rank's cyclic row tiles are rendered, in compact order."""
+        prm = abi.rt_params(max_depth, rank, world_size, 0)
+        W, H = camera.width(), camera.height()
+        rows = self.abi.rt_local_rows(H, C.byref(prm))
+        if rows < 0:
+            raise abi.RtError(abi.RT_ERR_INVALID, self.abi.rt_last_error().decode())
+        img = np.empty((rows, W, 3), dtype=np.float64)
+        st = abi.rt_stats()
+        self._check(self._f("render")(world.h, camera.h, device, C.byref(prm), img.ctypes.data_as(c_dp),
+                                      C.byref(st)))
+        return (img, st) if stats else img
+
+    def render_device(self, world, camera, d_ptr, stream=None, max_depth=5, device=0, rank=0, world_size=1):
+        """Asynchronous render into device memory at address d_ptr (e.g. a torch tensor's data_ptr)."""
+        prm = abi.rt_params(max_depth, rank, world_size, 0)
+        self._check(self._f("render_device")(world.h, camera.h, device, C.byref(prm), C.c_void_p(d_ptr),
+                                             C.c_void_p(stream or 0)))
+
+    def color_at(self, world, origins, directions, remaining=5, device=0, stats=False):
+        """World::color_at (src/scene/world.rs:198-212) for a batch of rays on the GPU."""
+        o = np.ascontiguousarray(origins, dtype=np.float64).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float64).reshape(-1, 3)
+        assert o.shape == d.shape
+        out = np.empty_like(o)
+        st = abi.rt_stats()
+        self._check(self._f("color_at")(world.h, device, o.shape[0], o.ctypes.data_as(c_dp),
+                                        d.ctypes.data_as(c_dp), remaining, out.ctypes.data_as(c_dp),
+                                        C.byref(st)))
+        return (out, st) if stats else out
+
+    def local_rows(self, height, rank, world_size):
+        prm = abi.rt_params(0, rank, world_size, 0)
+        return int(self.abi.rt_local_rows(height, C.byref(prm)))
+
+    def global_rows(self, height, rank, world_size):
+        """Frame row of every compact row of `rank`."""
+        prm = abi.rt_params(0, rank, world_size, 0)
+        n = self.local_rows(height, rank, world_size)
+        return np.array([self.abi.rt_global_row(i, C.byref(prm)) for i in range(n)], dtype=np.int64)
+
+    # ---- canvas -----------------------------------------------------------------------------------
+    def clamp(self, v):
+        return self._f("clamp_u8")(float(v))
+
+    def to_ppm(self, img):
+        """Canvas::to_ppm (src/window/canvas.rs:62-94) for an (H, W, 3) float64 image."""
+        img = np.ascontiguousarray(img, dtype=np.float64)
+        h, w = img.shape[:2]
+        n = self._f("to_ppm")(img.ctypes.data_as(c_dp), w, h)
+        buf = C.create_string_buffer(n)
+        self._f("ppm_copy")(buf)
+        return buf.raw[:n]
+
+
+_API = None
+
+
+def load():
+    global _API
+    if _API is None:
+        _API = HostApi()
+    return _API

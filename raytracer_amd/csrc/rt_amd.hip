@@ -1,0 +1,1290 @@
+// librt_amd: the per-pixel render path as one CDNA4 (gfx950) kernel, behind the C ABI of
+// include/rt_abi.h.
+//
+// Execution model
+//   * one lane = one pixel (or one caller-supplied ray), one wavefront = one 8x8 pixel tile,
+//     256-thread workgroups (4 tiles side by side); no LDS, no barriers, no matrix cores: the path
+//     has no dense contraction, it is scalar f64 arithmetic per ray.
+//   * scene traversal is wave-synchronous: the wavefront walks the pre-order node array with ONE
+//     uniform node index.  Node records, matrices, boxes and triangles are therefore fetched with
+//     scalar loads (constant address space) into SGPRs and cost no vector registers or vector
+//     memory traffic.  Each lane only keeps the index up to which it is masked off (`skip_until`),
+//     set when its ray misses a group's bounding box; when a wave-wide ballot shows that no lane
+//     is inside a group the whole subtree is skipped with the node's skip link.
+//   * recursion (reflection, refraction) is an explicit per-lane frame stack in scratch memory;
+//     results are combined in the reference's summation order so colours are bit-identical.
+//
+// Arithmetic contract: IEEE f64, reference operation order, no FMA contraction (the file is
+// compiled with -ffp-contract=off and carries the pragma below), correctly rounded / and sqrt.
+// pow and cos come from the device math library and may differ from the host libm in the last ulp.
+#include <hip/hip_runtime.h>
+
+#include <climits>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_abi.h"
+
+#pragma clang fp contract(off)
+
+#define RT_CONST __attribute__((address_space(4)))
+#define DI __device__ __forceinline__
+#define RT_EPS 0.00001  // src/lib.rs:22
+#define RT_MAX_FRAMES RT_MAX_DEPTH
+#define RT_PAT_STACK (RT_MAX_PATTERN_NEST + 1)
+
+namespace {
+
+struct DevScene {
+    const RT_CONST rt_node* nodes;
+    const RT_CONST rt_xform* xforms;
+    const RT_CONST rt_aabb* aabbs;
+    const RT_CONST rt_range* ranges;
+    const RT_CONST rt_tri* tris;
+    const RT_CONST rt_tri_normals* trin;
+    const RT_CONST rt_material* mats;
+    const RT_CONST rt_pattern* pats;
+    const RT_CONST double* patx;
+    const RT_CONST rt_light* lights;
+    int n_nodes;
+    int n_lights;
+    int all_cast_shadow;
+};
+
+struct DevJob {
+    // camera (src/scene/camera.rs)
+    int width, height;
+    double half_width, half_height, pixel_size;
+    double inv[12];
+    // partition
+    int rank, world_size, tiles_x, local_tile_rows;
+    int max_depth;
+    // ray-list mode (rt_color_at)
+    long long n_rays;
+    const double* ray_o;
+    const double* ray_d;
+};
+
+// ---------------------------------------------------------------------------------------------
+// 3-vector algebra in the reference's operation order (src/tuples/tuple.rs).  The w lane is
+// dropped: it is exactly 1 for points and 0 for vectors everywhere on this path, and the terms
+// it contributes are exact zeros.
+// ---------------------------------------------------------------------------------------------
+struct V3 {
+    double x, y, z;
+};
+DI V3 mk(double x, double y, double z) { return V3{x, y, z}; }
+DI V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DI V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DI V3 operator-(V3 a) { return mk(-a.x, -a.y, -a.z); }
+DI V3 operator*(V3 a, double s) { return mk(a.x * s, a.y * s, a.z * s); }
+DI V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DI V3 operator/(V3 a, double s) { return mk(a.x / s, a.y / s, a.z / s); }
+DI double dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }  // tuple.rs:75-80
+DI V3 cross(V3 a, V3 b) {                                                 // tuple.rs:83-92
+    return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+DI double magnitude(V3 a) { return sqrt(dot(a, a)); }  // tuple.rs:49-53
+DI V3 reflect(V3 in, V3 n) {                            // tuple.rs:94-99
+    double d = dot(in, n);
+    return in - (n * 2.0) * d;
+}
+
+// Matrix x tuple (src/matrices/matrix.rs:344-363) on rows 0..2 of an affine inverse.
+template <class P>
+DI V3 xpoint(P m, V3 p) {
+    return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+template <class P>
+DI V3 xvec(P m, V3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+template <class P>
+DI V3 xnormal(P t, V3 n) {
+    return mk(t[0] * n.x + t[1] * n.y + t[2] * n.z, t[3] * n.x + t[4] * n.y + t[5] * n.z,
+              t[6] * n.x + t[7] * n.y + t[8] * n.z);
+}
+
+// Applies, outermost first, the inverse transforms of the non-identity groups that enclose a node
+// whose `ctx` link is `ctx` (Shape::intersect applied level by level, src/geometry/shape.rs:23-29,
+// and Shape::world_to_object, shape.rs:65-79).  Identity levels are exact no-ops and are skipped.
+DI void chain_collect(const DevScene& S, int ctx, int c[RT_MAX_XFORM_NEST]) {
+    c[0] = ctx;
+#pragma unroll
+    for (int k = 1; k < RT_MAX_XFORM_NEST; ++k) c[k] = c[k - 1] >= 0 ? S.nodes[c[k - 1]].ctx : -1;
+}
+DI V3 chain_point(const DevScene& S, int ctx, V3 p) {
+    int c[RT_MAX_XFORM_NEST];
+    chain_collect(S, ctx, c);
+#pragma unroll
+    for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
+        if (c[k] >= 0) p = xpoint(S.xforms[S.nodes[c[k]].xform].inv, p);
+    return p;
+}
+DI void chain_ray(const DevScene& S, int ctx, V3& o, V3& d) {
+    int c[RT_MAX_XFORM_NEST];
+    chain_collect(S, ctx, c);
+#pragma unroll
+    for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
+        if (c[k] >= 0) {
+            const RT_CONST double* m = S.xforms[S.nodes[c[k]].xform].inv;
+            o = xpoint(m, o);
+            d = xvec(m, d);
+        }
+}
+
+// BoundingBox::check_axis / Cube::check_axis (bounding_box.rs:102-124, cube.rs:47-69).
+DI void check_axis(double origin, double direction, double mn, double mx, double& tmin, double& tmax) {
+    double a = mn - origin;
+    double b = mx - origin;
+    bool finite = fabs(direction) >= RT_EPS;
+    double t0 = finite ? a / direction : a * INFINITY;
+    double t1 = finite ? b / direction : b * INFINITY;
+    bool swap = t0 > t1;
+    tmin = swap ? t1 : t0;
+    tmax = swap ? t0 : t1;
+}
+// BoundingBox::intersects / Cube::local_intersect slab test: returns tmin, tmax.
+DI void slabs(V3 o, V3 d, double x0, double y0, double z0, double x1, double y1, double z1, double& tmin,
+              double& tmax) {
+    double xa, xb, ya, yb, za, zb;
+    check_axis(o.x, d.x, x0, x1, xa, xb);
+    check_axis(o.y, d.y, y0, y1, ya, yb);
+    check_axis(o.z, d.z, z0, z1, za, zb);
+    tmin = fmax(fmax(xa, ya), za);
+    tmax = fmin(fmin(xb, yb), zb);
+}
+
+// Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
+// for the n1/n2 bookkeeping, the parity and the latest of the leaf's non-positive times.
+struct LeafAcc {
+    double best;
+    bool found;
+    int par;
+    double negmax;
+};
+template <bool TRACK>
+DI void leaf_add(LeafAcc& a, double t) {
+    if (t > 0.0) {
+        if (!a.found || t < a.best) {
+            a.best = t;
+            a.found = true;
+        }
+    } else if (TRACK && t <= 0.0) {
+        a.par ^= 1;
+        a.negmax = fmax(a.negmax, t);
+    }
+}
+
+struct Hit {
+    bool found;
+    double t;
+    int node;
+    double u, v;
+    // World::prepare_computations container walk (world.rs:99-132), reduced to what decides
+    // n1/n2: whether the hit leaf has an odd number of earlier intersections, and the two
+    // leaves with an odd count whose last earlier intersection comes latest in sorted order.
+    int par;
+    double a_t, b_t;
+    int a_id, b_id;
+};
+
+DI int wave_min(int v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        int o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+enum { MODE_CLOSEST = 0, MODE_CLOSEST_TRACK = 1, MODE_SHADOW = 2 };
+
+// World::intersect_world + Intersection::hit for all lanes of the wavefront at once
+// (world.rs:55-68, group.rs:133-154 and the leaf local_intersect functions).  Must be called from
+// wave-uniform control flow; lanes without a ray pass active = false.
+// MODE_SHADOW: `limit` is the distance to the light; when every leaf casts a shadow a lane stops
+// at its first intersection in (0, limit) (any such intersection implies the nearest one is too).
+template <int MODE>
+DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
+    constexpr bool TRACK = MODE == MODE_CLOSEST_TRACK;
+    h.found = false;
+    h.t = 0.0;
+    h.node = -1;
+    h.u = 0.0;
+    h.v = 0.0;
+    h.par = 0;
+    h.a_t = 0.0;
+    h.b_t = 0.0;
+    h.a_id = -1;
+    h.b_id = -1;
+    if (__ballot(active) == 0ull) return;
+
+    int skip_until = active ? 0 : INT_MAX;
+    const int n = S.n_nodes;
+    int i = 0;
+    int cur_ctx = -1;
+    V3 co = wo, cd = wd;  // the ray in the space of group `cur_ctx`
+    const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
+
+    while (i < n) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        const int type = S.nodes[i].type;
+        const int xf = S.nodes[i].xform;
+        const int data = S.nodes[i].data;
+        const int skip = S.nodes[i].skip;
+        const int ctx = S.nodes[i].ctx;
+        if (ctx != cur_ctx) {
+            co = wo;
+            cd = wd;
+            chain_ray(S, ctx, co, cd);
+            cur_ctx = ctx;
+        }
+        const bool act = i >= skip_until;
+        V3 lo = co, ld = cd;
+        if (xf >= 0) {  // Shape::intersect: world_ray.transform(inverse) (shape.rs:24-26, ray.rs:30-35)
+            const RT_CONST double* m = S.xforms[xf].inv;
+            lo = xpoint(m, co);
+            ld = xvec(m, cd);
+        }
+        if (type == RT_GROUP) {
+            // Group::local_intersect (group.rs:133-154): bounds test in the group's own space.
+            const RT_CONST rt_aabb* bb = S.aabbs + data;
+            double tmin, tmax;
+            slabs(lo, ld, bb->min[0], bb->min[1], bb->min[2], bb->max[0], bb->max[1], bb->max[2], tmin, tmax);
+            bool inside = act && !(tmin > tmax);
+            if (act && !inside) skip_until = skip;
+            if (__ballot(inside) == 0ull) {
+                i = skip;
+            } else {
+                if (xf >= 0) {
+                    co = lo;
+                    cd = ld;
+                    cur_ctx = i;
+                }
+                i = i + 1;
+            }
+            continue;
+        }
+
+        LeafAcc acc;
+        acc.best = 0.0;
+        acc.found = false;
+        acc.par = 0;
+        acc.negmax = -INFINITY;
+        double hu = 0.0, hv = 0.0;
+        if (act) {
+            switch (type) {
+                case RT_SPHERE: {  // sphere.rs:52-78
+                    double a = dot(ld, ld);
+                    double b = 2.0 * dot(ld, lo);
+                    double c = dot(lo, lo) - 1.0;
+                    double disc = (b * b) - (4.0 * a * c);
+                    if (!(disc < 0.0)) {
+                        double sq = sqrt(disc);
+                        double den = a * 2.0;
+                        leaf_add<TRACK>(acc, (-b + sq) / den);
+                        leaf_add<TRACK>(acc, (-b - sq) / den);
+                    }
+                    break;
+                }
+                case RT_PLANE: {  // plane.rs:51-74
+                    if (!(fabs(ld.y) < RT_EPS)) leaf_add<TRACK>(acc, -lo.y / ld.y);
+                    break;
+                }
+                case RT_CUBE: {  // cube.rs:77-98
+                    double tmin, tmax;
+                    slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
+                    if (!(tmin > tmax)) {
+                        leaf_add<TRACK>(acc, tmin);
+                        leaf_add<TRACK>(acc, tmax);
+                    }
+                    break;
+                }
+                case RT_CYLINDER:
+                case RT_CONE: {  // cylinder.rs:62-153, cone.rs:63-163
+                    const bool cone = type == RT_CONE;
+                    const double mn = S.ranges[data].minimum;
+                    const double mx = S.ranges[data].maximum;
+                    const bool closed = (S.nodes[i].flags & RT_NODE_CLOSED) != 0;
+                    double a, b, c;
+                    bool walls, done = false;
+                    if (cone) {
+                        a = (ld.x * ld.x) - (ld.y * ld.y) + (ld.z * ld.z);
+                        b = (2.0 * lo.x * ld.x) - (2.0 * lo.y * ld.y) + (2.0 * lo.z * ld.z);
+                        c = (lo.x * lo.x) - (lo.y * lo.y) + (lo.z * lo.z);
+                        walls = !(fabs(a) < RT_EPS);
+                        if (!walls) {
+                            if (fabs(b) < RT_EPS) {
+                                done = true;  // misses walls and caps (cone.rs:119-121)
+                            } else {
+                                leaf_add<TRACK>(acc, -c / (2.0 * b));
+                            }
+                        }
+                    } else {
+                        a = ld.x * ld.x + ld.z * ld.z;
+                        b = (2.0 * lo.x * ld.x) + (2.0 * lo.z * ld.z);
+                        c = (lo.x * lo.x) + (lo.z * lo.z) - 1.0;
+                        walls = !(a < RT_EPS);
+                    }
+                    if (!done) {
+                        if (walls) {
+                            double disc = (b * b) - (4.0 * a * c);
+                            if (disc >= 0.0) {
+                                double sq = sqrt(disc);
+                                double t0 = (-b - sq) / (2.0 * a);
+                                double t1 = (-b + sq) / (2.0 * a);
+                                if (t0 > t1) {
+                                    double tmp = t0;
+                                    t0 = t1;
+                                    t1 = tmp;
+                                }
+                                double y0 = lo.y + t0 * ld.y;
+                                if (mn < y0 && y0 < mx) leaf_add<TRACK>(acc, t0);
+                                double y1 = lo.y + t1 * ld.y;
+                                if (mn < y1 && y1 < mx) leaf_add<TRACK>(acc, t1);
+                            }
+                        }
+                        if (closed && !(fabs(ld.y) < RT_EPS)) {  // intersect_caps
+                            double lim0 = cone ? fabs(mn) : 1.0;
+                            double lim1 = cone ? fabs(mx) : 1.0;
+                            double t0 = (mn - lo.y) / ld.y;
+                            double x = lo.x + t0 * ld.x, z = lo.z + t0 * ld.z;
+                            if (((x * x) + (z * z)) <= lim0) leaf_add<TRACK>(acc, t0);
+                            double t1 = (mx - lo.y) / ld.y;
+                            x = lo.x + t1 * ld.x;
+                            z = lo.z + t1 * ld.z;
+                            if (((x * x) + (z * z)) <= lim1) leaf_add<TRACK>(acc, t1);
+                        }
+                    }
+                    break;
+                }
+                default: {  // RT_TRIANGLE, RT_SMOOTH_TRIANGLE: triangle.rs:83-111, smooth_triangle.rs:101-129
+                    const RT_CONST rt_tri* tr = S.tris + data;
+                    V3 p1 = mk(tr->p1[0], tr->p1[1], tr->p1[2]);
+                    V3 e1 = mk(tr->e1[0], tr->e1[1], tr->e1[2]);
+                    V3 e2 = mk(tr->e2[0], tr->e2[1], tr->e2[2]);
+                    V3 dir_cross_e2 = cross(ld, e2);
+                    double det = dot(e1, dir_cross_e2);
+                    if (!(fabs(det) < RT_EPS)) {
+                        double f = 1.0 / det;
+                        V3 p1_to_origin = lo - p1;
+                        double u = f * dot(p1_to_origin, dir_cross_e2);
+                        if (!(u < 0.0 || u > 1.0)) {
+                            V3 origin_cross_e1 = cross(p1_to_origin, e1);
+                            double v = f * dot(ld, origin_cross_e1);
+                            if (!(v < 0.0 || (u + v) > 1.0)) {
+                                double t = f * dot(e2, origin_cross_e1);
+                                leaf_add<TRACK>(acc, t);
+                                hu = u;
+                                hv = v;
+                            }
+                        }
+                    }
+                    break;
+                }
+            }
+            // Stable sorts keep depth-first order among equal times, so a later leaf only wins
+            // with a strictly smaller time (group.rs:147, world.rs:65).
+            if (acc.found && (!h.found || acc.best < h.t)) {
+                h.found = true;
+                h.t = acc.best;
+                h.node = i;
+                h.u = hu;
+                h.v = hv;
+                h.par = acc.par;
+            }
+            if (TRACK && acc.par) {
+                if (h.a_id < 0 || acc.negmax >= h.a_t) {
+                    h.b_t = h.a_t;
+                    h.b_id = h.a_id;
+                    h.a_t = acc.negmax;
+                    h.a_id = i;
+                } else if (h.b_id < 0 || acc.negmax >= h.b_t) {
+                    h.b_t = acc.negmax;
+                    h.b_id = i;
+                }
+            }
+            if (early && h.found && h.t < limit) skip_until = INT_MAX;  // this lane is decided
+        }
+        i = i + 1;
+        if (early && __ballot(i >= skip_until) == 0ull) {
+            i = wave_min(skip_until);  // INT_MAX when every lane is decided: the loop ends
+        }
+    }
+}
+
+// Shape::normal_to_world (shape.rs:83-98): per level inverse-transpose, w := 0, normalise, then
+// the parent.  Identity levels skip the product but not the normalisation; once the magnitude is
+// exactly 1.0 further identity levels cannot change the vector, so the walk jumps to the next
+// enclosing non-identity group.
+DI V3 normal_to_world(const DevScene& S, int node, V3 n) {
+    int cur = node;
+    while (cur >= 0) {
+        int xf = S.nodes[cur].xform;
+        if (xf >= 0) n = xnormal(S.xforms[xf].inv_t, n);
+        double m = magnitude(n);
+        n = n / m;
+        cur = (m == 1.0) ? S.nodes[cur].ctx : S.nodes[cur].parent;
+    }
+    return n;
+}
+
+// Improved-noise permutation (Ken Perlin, 2002), as used by patterns/perturbed.rs:8-34.
+__constant__ unsigned char PERLIN_PERM[256] = {
+    151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103,
+    30,  69,  142, 8,   99,  37,  240, 21,  10,  23,  190, 6,   148, 247, 120, 234, 75,  0,   26,
+    197, 62,  94,  252, 219, 203, 117, 35,  11,  32,  57,  177, 33,  88,  237, 149, 56,  87,  174,
+    20,  125, 136, 171, 168, 68,  175, 74,  165, 71,  134, 139, 48,  27,  166, 77,  146, 158, 231,
+    83,  111, 229, 122, 60,  211, 133, 230, 220, 105, 92,  41,  55,  46,  245, 40,  244, 102, 143,
+    54,  65,  25,  63,  161, 1,   216, 80,  73,  209, 76,  132, 187, 208, 89,  18,  169, 200, 196,
+    135, 130, 116, 188, 159, 86,  164, 100, 109, 198, 173, 186, 3,   64,  52,  217, 226, 250, 124,
+    123, 5,   202, 38,  147, 118, 126, 255, 82,  85,  212, 207, 206, 59,  227, 47,  16,  58,  17,
+    182, 189, 28,  42,  223, 183, 170, 213, 119, 248, 152, 2,   44,  154, 163, 70,  221, 153, 101,
+    155, 167, 43,  172, 9,   129, 22,  39,  253, 19,  98,  108, 110, 79,  113, 224, 232, 178, 185,
+    112, 104, 218, 246, 97,  228, 251, 34,  242, 193, 238, 210, 144, 12,  191, 179, 162, 241, 81,
+    51,  145, 235, 249, 14,  239, 107, 49,  192, 214, 31,  181, 199, 106, 157, 184, 84,  204, 176,
+    115, 121, 50,  45,  127, 4,   150, 254, 138, 236, 205, 93,  222, 114, 67,  29,  24,  72,  243,
+    141, 128, 195, 78,  66,  215, 61,  156, 180};
+DI long long perm(long long i) { return (long long)PERLIN_PERM[i & 255]; }
+
+// Rust `as i64` on finite moderate values; NaN -> 0.
+DI long long to_i64(double v) { return (v != v) ? 0ll : (long long)v; }
+
+DI double fade(double t) { return t * t * t * (t * (t * 6.0 - 15.0) + 10.0); }  // perturbed.rs:59-61
+DI double lerp(double t, double a, double b) { return a + t * (b - a); }        // perturbed.rs:63-65
+DI double grad(long long hash, double x, double y, double z) {                  // perturbed.rs:68-82
+    long long hh = hash & 15;
+    double u = hh < 8 ? x : y;
+    double v = hh < 4 ? y : ((hh == 12 || hh == 14) ? x : z);
+    return ((hh & 1) == 0 ? u : -u) + ((hh & 2) == 0 ? v : -v);
+}
+DI double perlin(V3 p) {  // perturbed.rs:85-139
+    double fx = floor(p.x), fy = floor(p.y), fz = floor(p.z);
+    long long X = to_i64(fx) & 255, Y = to_i64(fy) & 255, Z = to_i64(fz) & 255;
+    double x = p.x - fx, y = p.y - fy, z = p.z - fz;
+    double u = fade(x), v = fade(y), w = fade(z);
+    long long A = perm(X) + Y, AA = perm(A) + Z, AB = perm(A + 1) + Z;
+    long long B = perm(X + 1) + Y, BA = perm(B) + Z, BB = perm(B + 1) + Z;
+    return lerp(w,
+                lerp(v, lerp(u, grad(perm(AA), x, y, z), grad(perm(BA), x - 1.0, y, z)),
+                     lerp(u, grad(perm(AB), x, y - 1.0, z), grad(perm(BB), x - 1.0, y - 1.0, z))),
+                lerp(v, lerp(u, grad(perm(AA + 1), x, y, z - 1.0), grad(perm(BA + 1), x - 1.0, y, z - 1.0)),
+                     lerp(u, grad(perm(AB + 1), x, y - 1.0, z - 1.0),
+                          grad(perm(BB + 1), x - 1.0, y - 1.0, z - 1.0))));
+}
+
+// Pattern::local_pattern_at on the pattern tree (pattern.rs:16-22 and the pattern_at
+// implementations), as an explicit-stack walk: selecting patterns (striped, ring, checker,
+// perturbed) continue into one child; gradient and blended evaluate both children.
+DI V3 pattern_eval(const DevScene& S, int root, V3 p) {
+    int st_node[RT_PAT_STACK];
+    int st_state[RT_PAT_STACK];
+    V3 st_p[RT_PAT_STACK];
+    V3 st_c[RT_PAT_STACK];
+    int sp = 0;
+    int cur = root;
+    V3 result = mk(0.0, 0.0, 0.0);
+    for (;;) {
+        // descend
+        for (;;) {
+            int type = S.pats[cur].type;
+            int xf = S.pats[cur].xform;
+            if (xf >= 0) p = xpoint(S.patx + (long long)xf * 12, p);
+            if (type == RT_PAT_SOLID) {
+                result = mk(S.pats[cur].color[0], S.pats[cur].color[1], S.pats[cur].color[2]);
+                break;
+            } else if (type == RT_PAT_TEST) {
+                result = p;
+                break;
+            } else if (type == RT_PAT_STRIPED) {  // striped.rs:36-45
+                cur = (to_i64(floor(p.x)) % 2 == 0) ? S.pats[cur].a : S.pats[cur].b;
+            } else if (type == RT_PAT_RING) {  // ring.rs:32-44
+                double xs = p.x * p.x, zs = p.z * p.z;
+                cur = (to_i64(sqrt(xs + zs)) % 2 == 0) ? S.pats[cur].a : S.pats[cur].b;
+            } else if (type == RT_PAT_CHECKER) {  // checker.rs:36-49
+                double s = floor(p.x) + floor(p.y) + floor(p.z);
+                cur = (to_i64(s) % 2 == 0) ? S.pats[cur].a : S.pats[cur].b;
+            } else if (type == RT_PAT_PERTURBED) {  // perturbed.rs:142-158
+                double nz = perlin(p) * S.pats[cur].scale;
+                p = mk(p.x + nz, p.y + nz, p.z + nz);
+                cur = S.pats[cur].a;
+            } else {  // gradient / blended: former first
+                if (sp >= RT_PAT_STACK) {  // cannot happen: nesting is validated on the host
+                    result = mk(0.0, 0.0, 0.0);
+                    break;
+                }
+                st_node[sp] = cur;
+                st_state[sp] = 0;
+                st_p[sp] = p;
+                ++sp;
+                cur = S.pats[cur].a;
+            }
+        }
+        // ascend
+        for (;;) {
+            if (sp == 0) return result;
+            int f = sp - 1;
+            if (st_state[f] == 0) {
+                st_c[f] = result;
+                st_state[f] = 1;
+                cur = S.pats[st_node[f]].b;
+                p = st_p[f];
+                break;  // descend into the latter pattern
+            }
+            V3 fc = st_c[f], lc = result;
+            if (S.pats[st_node[f]].type == RT_PAT_GRADIENT) {  // gradient.rs:36-47
+                V3 distance = lc - fc;
+                double fraction = st_p[f].x - floor(st_p[f].x);
+                result = fc + (distance * fraction);
+            } else {  // blended.rs:36-44
+                result = (fc + lc) / 2.0;
+            }
+            --sp;
+        }
+    }
+}
+
+// World::schlick (world.rs:279-302), including its use of cos() where the textbook has sqrt().
+DI double schlick(double cosv, double n1, double n2) {
+    if (n1 > n2) {
+        double n = n1 / n2;
+        double sin2_t = (n * n) * (1.0 - (cosv * cosv));
+        if (sin2_t > 1.0) return 1.0;
+        cosv = cos(1.0 - sin2_t);
+    }
+    double q = (n1 - n2) / (n1 + n2);
+    double r0 = q * q;
+    double m = 1.0 - cosv;
+    double m2 = m * m;
+    double m5 = m * (m2 * m2);
+    return r0 + (1.0 - r0) * m5;
+}
+
+// One suspended color_at call that is waiting for its reflected / refracted colour
+// (World::shade_hit, world.rs:162-196).
+struct Frame {
+    double surf[RT_MAX_LIGHTS][3];  // surface colour per light, in light order
+    double refl[3];                 // reflected colour * reflective
+    double rray[6];                 // pending refraction ray (under_point, direction)
+    double k;                       // Schlick reflectance
+    double transparency;
+    double reflective;
+    int state;                      // bit0: waiting for refraction (else reflection); bit1: refraction still to trace; bit2: use Schlick
+};
+
+// ((acc + surface) + reflected [* k]) + refracted [* (1 - k)] per light, world.rs:183-192.
+DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
+    V3 acc = mk(0.0, 0.0, 0.0);
+    const bool use_k = (f.state & 4) != 0;
+    V3 a = use_k ? refl * f.k : refl;
+    V3 b = use_k ? refr * (1.0 - f.k) : refr;
+    for (int l = 0; l < n_lights; ++l) {
+        V3 s = mk(f.surf[l][0], f.surf[l][1], f.surf[l][2]);
+        acc = acc + s + a + b;
+    }
+    return acc;
+}
+
+template <bool TRACK>
+__global__ void __launch_bounds__(256) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
+                                                 unsigned long long* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+
+    bool pending;
+    long long out_index;
+    V3 ro, rd;
+    if (J.n_rays > 0) {
+        // World::color_at for caller-supplied rays.
+        long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        pending = r < J.n_rays;
+        long long rr = pending ? r : 0;
+        ro = mk(J.ray_o[rr * 3], J.ray_o[rr * 3 + 1], J.ray_o[rr * 3 + 2]);
+        rd = mk(J.ray_d[rr * 3], J.ray_d[rr * 3 + 1], J.ray_d[rr * 3 + 2]);
+        out_index = rr;
+    } else {
+        // Workgroups are dealt round-robin to the 8 XCDs; remap so that each XCD renders a
+        // contiguous band of tiles and its L2 sees a spatially coherent part of the scene.
+        const unsigned nwg = gridDim.x;
+        unsigned b = blockIdx.x;
+        {
+            unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
+            b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        }
+        const long long tile = (long long)b * 4 + wave;
+        const int tx = (int)(tile % J.tiles_x);
+        const int lty = (int)(tile / J.tiles_x);
+        const int px = tx * RT_TILE + (lane & 7);
+        const int local_y = lty * RT_TILE + (lane >> 3);
+        const int py = (lty * J.world_size + J.rank) * RT_TILE + (lane >> 3);
+        pending = lty < J.local_tile_rows && px < J.width && py < J.height;
+        out_index = (long long)local_y * J.width + px;
+        // Camera::ray_for_pixel (camera.rs:47-66)
+        double x_offset = ((double)px + 0.5) * J.pixel_size;
+        double y_offset = ((double)py + 0.5) * J.pixel_size;
+        double world_x = J.half_width - x_offset;
+        double world_y = J.half_height - y_offset;
+        V3 pixel = xpoint(J.inv, mk(world_x, world_y, -1.0));
+        V3 origin = mk(J.inv[3], J.inv[7], J.inv[11]);
+        V3 dirv = pixel - origin;
+        double m = magnitude(dirv);
+        ro = origin;
+        rd = dirv / m;
+    }
+    const bool valid = pending;
+
+    unsigned n_primary = pending ? 1u : 0u, n_shadow = 0u, n_reflect = 0u, n_refract = 0u;
+    Frame frames[RT_MAX_FRAMES];
+    int sp = 0;  // suspended calls; the ray being traced has remaining = max_depth - sp
+    V3 final_colour = mk(0.0, 0.0, 0.0);
+    const int L = S.n_lights;
+
+    while (__ballot(pending) != 0ull) {
+        Hit h;
+        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST>(S, pending, ro, rd, 0.0, h);
+        const bool shade = pending && h.found;
+
+        // ---- World::prepare_computations (world.rs:70-147) --------------------------------
+        V3 over = mk(0.0, 0.0, 0.0), under = over, eyev = over, normalv = over, reflectv = over;
+        V3 colour = over;
+        double n1 = 1.0, n2 = 1.0;
+        double ka = 0.0, kd = 0.0, ks = 0.0, shin = 0.0, refl_c = 0.0, transp = 0.0;
+        if (shade) {
+            const int node = h.node;
+            const int type = S.nodes[node].type;
+            const int xf = S.nodes[node].xform;
+            const int data = S.nodes[node].data;
+            const int ctx = S.nodes[node].ctx;
+            const int mat = S.nodes[node].material;
+            V3 point = ro + (rd * h.t);  // Ray::position (ray.rs:24-26)
+            eyev = -rd;
+            // Shape::normal_at (shape.rs:52-59)
+            V3 lp = chain_point(S, ctx, point);
+            if (xf >= 0) lp = xpoint(S.xforms[xf].inv, lp);
+            V3 ln;
+            switch (type) {
+                case RT_SPHERE:  // sphere.rs:109-111
+                    ln = lp;
+                    break;
+                case RT_PLANE:  // plane.rs:105-107: the plane's own inverse times (0, 1, 0)
+                    ln = xf >= 0 ? mk(S.xforms[xf].inv[1], S.xforms[xf].inv[5], S.xforms[xf].inv[9])
+                                 : mk(0.0, 1.0, 0.0);
+                    break;
+                case RT_CUBE: {  // cube.rs:129-142
+                    double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+                    double maxc = fmax(fmax(ax, ay), az);
+                    if (maxc == ax)
+                        ln = mk(lp.x, 0.0, 0.0);
+                    else if (maxc == ay)
+                        ln = mk(0.0, lp.y, 0.0);
+                    else
+                        ln = mk(0.0, 0.0, lp.z);
+                    break;
+                }
+                case RT_CYLINDER:
+                case RT_CONE: {  // cylinder.rs:184-197, cone.rs:194-213
+                    double mn = S.ranges[data].minimum, mx = S.ranges[data].maximum;
+                    double dist = lp.x * lp.x + lp.z * lp.z;
+                    if (dist < 1.0 && lp.y >= mx - RT_EPS) {
+                        ln = mk(0.0, 1.0, 0.0);
+                    } else if (dist < 1.0 && lp.y <= mn + RT_EPS) {
+                        ln = mk(0.0, -1.0, 0.0);
+                    } else if (type == RT_CYLINDER) {
+                        ln = mk(lp.x, 0.0, lp.z);
+                    } else {
+                        double y = sqrt(dist);
+                        ln = mk(lp.x, lp.y > 0.0 ? -y : y, lp.z);
+                    }
+                    break;
+                }
+                case RT_TRIANGLE:  // triangle.rs:142-144
+                    ln = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
+                    break;
+                default: {  // smooth_triangle.rs:160-162
+                    V3 a1 = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
+                    V3 a2 = mk(S.trin[data].n2[0], S.trin[data].n2[1], S.trin[data].n2[2]);
+                    V3 a3 = mk(S.trin[data].n3[0], S.trin[data].n3[1], S.trin[data].n3[2]);
+                    ln = (a2 * h.u) + (a3 * h.v) + (a1 * (1.0 - h.u - h.v));
+                    break;
+                }
+            }
+            normalv = normal_to_world(S, node, ln);
+            if (dot(normalv, eyev) < 0.0) normalv = -normalv;
+            reflectv = reflect(rd, normalv);
+            over = point + (normalv * RT_EPS);
+            under = point - (normalv * RT_EPS);
+            if (TRACK) {
+                // Refractive indices of the last container before / after the hit (world.rs:103-132).
+                const int x_id = (h.a_id != node) ? h.a_id : h.b_id;  // latest container other than the hit leaf
+                const double ri_hit = S.mats[mat].refractive_index;
+                const double ri_x = x_id >= 0 ? S.mats[S.nodes[x_id].material].refractive_index : 1.0;
+                if (h.par) {  // the hit leaf is itself an open container: this is an exit
+                    n1 = S.mats[S.nodes[h.a_id].material].refractive_index;
+                    n2 = ri_x;
+                } else {
+                    n1 = ri_x;
+                    n2 = ri_hit;
+                }
+            }
+            ka = S.mats[mat].ambient;
+            kd = S.mats[mat].diffuse;
+            ks = S.mats[mat].specular;
+            shin = S.mats[mat].shininess;
+            refl_c = S.mats[mat].reflective;
+            transp = S.mats[mat].transparency;
+            // Pattern::pattern_at_shape at over_point (phong.rs:68, pattern.rs:8-14)
+            const int pat = S.mats[mat].pattern;
+            if (S.pats[pat].type == RT_PAT_SOLID) {
+                colour = mk(S.pats[pat].color[0], S.pats[pat].color[1], S.pats[pat].color[2]);
+            } else {
+                V3 op = chain_point(S, ctx, over);
+                if (xf >= 0) op = xpoint(S.xforms[xf].inv, op);
+                colour = pattern_eval(S, pat, op);
+            }
+        }
+
+        // ---- which secondary rays this hit needs (world.rs:214-275) --------------------------
+        const int remaining = J.max_depth - sp;
+        bool want_refl = false, want_refr = false, use_k = false;
+        V3 refr_dir = mk(0.0, 0.0, 0.0);
+        double kk = 0.0;
+        if (shade) {
+            want_refl = remaining > 0 && !(fabs(refl_c - 0.0) < RT_EPS);
+            if (TRACK) {
+                if (remaining > 0 && !(fabs(transp - 0.0) < RT_EPS)) {
+                    double n_ratio = n1 / n2;
+                    double cos_i = dot(eyev, normalv);
+                    double sin2_t = (n_ratio * n_ratio) * (1.0 - (cos_i * cos_i));
+                    if (!(sin2_t > 1.0)) {
+                        double cos_t = sqrt(1.0 - sin2_t);
+                        refr_dir = normalv * (n_ratio * cos_i - cos_t) - eyev * n_ratio;
+                        want_refr = true;
+                    }
+                }
+                use_k = refl_c > 0.0 && transp > 0.0;
+                if (use_k && (want_refl || want_refr)) kk = schlick(dot(eyev, normalv), n1, n2);
+            }
+        }
+        const bool has_children = want_refl || want_refr;
+
+        // ---- per light: World::is_shadowed + Phong::lighting (world.rs:304-326, phong.rs:59-116)
+        V3 acc = mk(0.0, 0.0, 0.0);
+        for (int l = 0; l < L; ++l) {
+            V3 lpos = mk(S.lights[l].position[0], S.lights[l].position[1], S.lights[l].position[2]);
+            V3 lint = mk(S.lights[l].intensity[0], S.lights[l].intensity[1], S.lights[l].intensity[2]);
+            V3 lv = lpos - over;
+            double distance = magnitude(lv);
+            V3 lightv = lv / distance;
+            Hit sh;
+            trace<MODE_SHADOW>(S, shade, over, lightv, distance, sh);
+            if (shade) {
+                ++n_shadow;
+                bool in_shadow = sh.found && sh.t < distance &&
+                                 (S.all_cast_shadow || (S.nodes[sh.node].flags & RT_NODE_CASTS_SHADOW));
+                V3 effective = colour * lint;
+                V3 ambient = effective * ka;
+                V3 surf = ambient;
+                if (!in_shadow) {
+                    V3 diffuse = mk(0.0, 0.0, 0.0), specular = diffuse;
+                    double ldn = dot(lightv, normalv);
+                    if (!(ldn < 0.0)) {
+                        diffuse = effective * kd * ldn;
+                        V3 rv = reflect(-lightv, normalv);
+                        double rde = dot(rv, eyev);
+                        if (!(rde <= 0.0)) {
+                            // a zero specular coefficient makes the term an exact zero; skip pow
+                            double factor = (ks == 0.0) ? 1.0 : pow(rde, shin);
+                            specular = lint * ks * factor;
+                        }
+                    }
+                    surf = ambient + diffuse + specular;
+                }
+                if (has_children) {
+                    frames[sp].surf[l][0] = surf.x;
+                    frames[sp].surf[l][1] = surf.y;
+                    frames[sp].surf[l][2] = surf.z;
+                } else {
+                    acc = acc + surf;  // + black + black: exact no-ops (world.rs:191)
+                }
+            }
+        }
+
+        // ---- suspend, or return the colour up the stack ----------------------------------------
+        if (pending) {
+            V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
+            bool returning = true;
+            if (shade && has_children) {
+                Frame& f = frames[sp];
+                f.k = kk;
+                f.reflective = refl_c;
+                f.transparency = transp;
+                f.rray[0] = under.x;
+                f.rray[1] = under.y;
+                f.rray[2] = under.z;
+                f.rray[3] = refr_dir.x;
+                f.rray[4] = refr_dir.y;
+                f.rray[5] = refr_dir.z;
+                if (want_refl) {
+                    f.state = (want_refr ? 2 : 0) | (use_k ? 4 : 0);
+                    ro = over;
+                    rd = reflectv;
+                    ++n_reflect;
+                } else {
+                    f.refl[0] = 0.0;
+                    f.refl[1] = 0.0;
+                    f.refl[2] = 0.0;
+                    f.state = 1 | (use_k ? 4 : 0);
+                    ro = under;
+                    rd = refr_dir;
+                    ++n_refract;
+                }
+                ++sp;
+                returning = false;
+            }
+            while (returning) {
+                if (sp == 0) {
+                    final_colour = value;
+                    pending = false;
+                    break;
+                }
+                Frame& f = frames[sp - 1];
+                if ((f.state & 1) == 0) {
+                    // the reflected colour arrived (world.rs:228-230)
+                    V3 refl = value * f.reflective;
+                    if (f.state & 2) {
+                        f.refl[0] = refl.x;
+                        f.refl[1] = refl.y;
+                        f.refl[2] = refl.z;
+                        f.state = (f.state & 4) | 1;
+                        ro = mk(f.rray[0], f.rray[1], f.rray[2]);
+                        rd = mk(f.rray[3], f.rray[4], f.rray[5]);
+                        ++n_refract;
+                        break;  // trace the refraction ray next
+                    }
+                    value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
+                } else {
+                    // the refracted colour arrived (world.rs:274)
+                    V3 refr = value * f.transparency;
+                    value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                }
+                --sp;
+            }
+        }
+    }
+
+    if (valid) {
+        out[out_index * 3] = final_colour.x;
+        out[out_index * 3 + 1] = final_colour.y;
+        out[out_index * 3 + 2] = final_colour.z;
+    }
+    // ray statistics: one atomic per wavefront and counter
+    unsigned c[4] = {n_primary, n_shadow, n_reflect, n_refract};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        unsigned v = c[k];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0 && v) atomicAdd(&counters[k], (unsigned long long)v);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Host side of the C ABI
+// ---------------------------------------------------------------------------------------------
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess)                                                                      \
+            return fail(RT_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));            \
+    } while (0)
+
+constexpr int TIMING_RING = 256;
+
+}  // namespace
+
+struct rt_scene {
+    int device = 0;
+    DevScene dev{};
+    bool any_transparent = false;
+    std::vector<void*> allocations;
+    unsigned long long* d_counters = nullptr;
+    double* d_frame = nullptr;  // staging for the synchronous entry points
+    size_t frame_bytes = 0;
+    double* d_rays = nullptr;
+    size_t rays_bytes = 0;
+    hipEvent_t ev_start[TIMING_RING] = {};
+    hipEvent_t ev_stop[TIMING_RING] = {};
+    long long launches = 0;
+    hipStream_t last_stream = nullptr;
+};
+
+namespace {
+
+template <class T>
+int upload(rt_scene* s, const T* src, size_t count, const RT_CONST T** dst) {
+    void* p = nullptr;
+    size_t bytes = (count ? count : 1) * sizeof(T);
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->allocations.push_back(p);
+    if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    *dst = (const RT_CONST T*)p;
+    return RT_OK;
+}
+
+int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
+    if (!d) return fail(RT_ERR_INVALID, "null scene description");
+    if (d->n_nodes < 0 || d->n_xforms < 0 || d->n_aabbs < 0 || d->n_ranges < 0 || d->n_tris < 0 ||
+        d->n_materials < 0 || d->n_patterns < 0 || d->n_pattern_xforms < 0 || d->n_lights < 0)
+        return fail(RT_ERR_INVALID, "negative table size");
+    if ((d->n_nodes && !d->nodes) || (d->n_xforms && !d->xforms) || (d->n_aabbs && !d->aabbs) ||
+        (d->n_ranges && !d->ranges) || (d->n_tris && (!d->tris || !d->tri_normals)) ||
+        (d->n_materials && !d->materials) || (d->n_patterns && !d->patterns) ||
+        (d->n_pattern_xforms && !d->pattern_xforms) || (d->n_lights && !d->lights))
+        return fail(RT_ERR_INVALID, "null table with non-zero size");
+    if (d->n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_LIMIT, "more than RT_MAX_LIGHTS lights");
+    all_cast = true;
+    for (int i = 0; i < d->n_nodes; ++i) {
+        const rt_node& n = d->nodes[i];
+        auto bad = [&](const char* what) {
+            return fail(RT_ERR_INVALID, "node " + std::to_string(i) + ": " + what);
+        };
+        if (n.type < RT_GROUP || n.type > RT_SMOOTH_TRIANGLE) return bad("unknown type");
+        if (n.parent < -1 || n.parent >= i) return bad("parent must precede the node");
+        if (n.parent >= 0 && d->nodes[n.parent].type != RT_GROUP) return bad("parent is not a group");
+        if (n.skip <= i || n.skip > d->n_nodes) return bad("bad skip link");
+        if (n.parent >= 0 && n.skip > d->nodes[n.parent].skip) return bad("subtree leaves its parent");
+        if (n.type != RT_GROUP && n.skip != i + 1) return bad("leaf with a subtree");
+        if (n.xform < -1 || n.xform >= d->n_xforms) return bad("xform out of range");
+        if (n.ctx < -1 || n.ctx >= i) return bad("ctx must precede the node");
+        // ctx must be the nearest enclosing group with a transform
+        int expect = -1;
+        for (int p = n.parent; p >= 0; p = d->nodes[p].parent)
+            if (d->nodes[p].xform >= 0) {
+                expect = p;
+                break;
+            }
+        if (n.ctx != expect) return bad("ctx is not the nearest transformed ancestor");
+        int depth = 0;
+        for (int c = n.ctx; c >= 0; c = d->nodes[c].ctx) ++depth;
+        if (depth > RT_MAX_XFORM_NEST) return fail(RT_ERR_LIMIT, "transformed groups nested too deeply");
+        switch (n.type) {
+            case RT_GROUP:
+                if (n.data < 0 || n.data >= d->n_aabbs) return bad("aabb out of range");
+                break;
+            case RT_CYLINDER:
+            case RT_CONE:
+                if (n.data < 0 || n.data >= d->n_ranges) return bad("range out of range");
+                break;
+            case RT_TRIANGLE:
+            case RT_SMOOTH_TRIANGLE:
+                if (n.data < 0 || n.data >= d->n_tris) return bad("triangle out of range");
+                break;
+            default:
+                break;
+        }
+        if (n.type != RT_GROUP) {
+            if (n.material < 0 || n.material >= d->n_materials) return bad("material out of range");
+            if (!(n.flags & RT_NODE_CASTS_SHADOW)) all_cast = false;
+        }
+    }
+    any_transparent = false;
+    for (int i = 0; i < d->n_materials; ++i) {
+        const rt_material& m = d->materials[i];
+        if (m.pattern < 0 || m.pattern >= d->n_patterns)
+            return fail(RT_ERR_INVALID, "material " + std::to_string(i) + ": pattern out of range");
+        if (m.transparency != 0.0) any_transparent = true;
+    }
+    for (int i = 0; i < d->n_patterns; ++i) {
+        const rt_pattern& p = d->patterns[i];
+        auto bad = [&](const char* what) {
+            return fail(RT_ERR_INVALID, "pattern " + std::to_string(i) + ": " + what);
+        };
+        if (p.type < RT_PAT_SOLID || p.type > RT_PAT_TEST) return bad("unknown type");
+        if (p.xform < -1 || p.xform >= d->n_pattern_xforms) return bad("xform out of range");
+        const bool binary = p.type >= RT_PAT_STRIPED && p.type <= RT_PAT_BLENDED;
+        // children must follow their parent, which rules out cycles
+        if (binary || p.type == RT_PAT_PERTURBED)
+            if (p.a <= i || p.a >= d->n_patterns) return bad("child a must follow the pattern");
+        if (binary)
+            if (p.b <= i || p.b >= d->n_patterns) return bad("child b must follow the pattern");
+    }
+    // nesting of two-child evaluating patterns (children have larger indices: go backwards)
+    {
+        std::vector<int> nest(d->n_patterns, 0);
+        for (int i = d->n_patterns - 1; i >= 0; --i) {
+            const rt_pattern& p = d->patterns[i];
+            int below = 0;
+            if (p.type != RT_PAT_SOLID && p.type != RT_PAT_TEST) {
+                below = nest[p.a];
+                if (p.type != RT_PAT_PERTURBED && nest[p.b] > below) below = nest[p.b];
+            }
+            nest[i] = below + ((p.type == RT_PAT_GRADIENT || p.type == RT_PAT_BLENDED) ? 1 : 0);
+            if (nest[i] > RT_MAX_PATTERN_NEST)
+                return fail(RT_ERR_LIMIT, "gradient/blended patterns nested too deeply");
+        }
+    }
+    return RT_OK;
+}
+
+int check_params(const rt_params* p) {
+    if (!p) return fail(RT_ERR_INVALID, "null params");
+    if (p->world_size < 1 || p->rank < 0 || p->rank >= p->world_size)
+        return fail(RT_ERR_INVALID, "rank/world_size out of range");
+    if (p->max_depth < 0 || p->max_depth > RT_MAX_DEPTH)
+        return fail(RT_ERR_LIMIT, "max_depth outside 0..RT_MAX_DEPTH");
+    return RT_OK;
+}
+
+int local_tile_rows(int height, const rt_params* p) {
+    int tile_rows = (height + RT_TILE - 1) / RT_TILE;
+    if (p->rank >= tile_rows) return 0;
+    return (tile_rows - p->rank + p->world_size - 1) / p->world_size;
+}
+
+int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipStream_t stream) {
+    int slot = (int)(s->launches % TIMING_RING);
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
+    if (blocks > 0) {
+        if (s->any_transparent)
+            hipLaunchKernelGGL(rt_kernel<true>, dim3(blocks), dim3(256), 0, stream, s->dev, job, d_out,
+                               s->d_counters);
+        else
+            hipLaunchKernelGGL(rt_kernel<false>, dim3(blocks), dim3(256), 0, stream, s->dev, job, d_out,
+                               s->d_counters);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(s->ev_stop[slot], stream));
+    s->launches++;
+    s->last_stream = stream;
+    return RT_OK;
+}
+
+int fill_stats(rt_scene* s, rt_stats* st) {
+    if (!st) return RT_OK;
+    unsigned long long c[4];
+    HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    st->rays_primary = c[0];
+    st->rays_shadow = c[1];
+    st->rays_reflect = c[2];
+    st->rays_refract = c[3];
+    st->kernel_ms = 0.0f;
+    st->reserved = 0.0f;
+    if (s->launches > 0) {
+        int slot = (int)((s->launches - 1) % TIMING_RING);
+        HIP_TRY(hipEventSynchronize(s->ev_stop[slot]));
+        HIP_TRY(hipEventElapsedTime(&st->kernel_ms, s->ev_start[slot], s->ev_stop[slot]));
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_error.c_str(); }
+
+int rt_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null out pointer");
+    *out = nullptr;
+    bool all_cast = true, any_transparent = false;
+    int rc = validate(d, all_cast, any_transparent);
+    if (rc != RT_OK) return rc;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    rt_scene* s = new rt_scene();
+    s->device = device;
+    s->any_transparent = any_transparent;
+    auto cleanup = [&](int code) {
+        rt_scene_destroy(s);
+        return code;
+    };
+    if ((rc = upload(s, d->nodes, d->n_nodes, &s->dev.nodes)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->aabbs, d->n_aabbs, &s->dev.aabbs)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->ranges, d->n_ranges, &s->dev.ranges)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->tris, d->n_tris, &s->dev.tris)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->tri_normals, d->n_tris, &s->dev.trin)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->materials, d->n_materials, &s->dev.mats)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->patterns, d->n_patterns, &s->dev.pats)) != RT_OK) return cleanup(rc);
+    if ((rc = upload(s, d->pattern_xforms, (size_t)d->n_pattern_xforms * 12, &s->dev.patx)) != RT_OK)
+        return cleanup(rc);
+    if ((rc = upload(s, d->lights, d->n_lights, &s->dev.lights)) != RT_OK) return cleanup(rc);
+    s->dev.n_nodes = d->n_nodes;
+    s->dev.n_lights = d->n_lights;
+    s->dev.all_cast_shadow = all_cast ? 1 : 0;
+    void* p = nullptr;
+    if (hipMalloc(&p, 4 * sizeof(unsigned long long)) != hipSuccess)
+        return cleanup(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
+    s->d_counters = (unsigned long long*)p;
+    for (int i = 0; i < TIMING_RING; ++i) {
+        if (hipEventCreate(&s->ev_start[i]) != hipSuccess || hipEventCreate(&s->ev_stop[i]) != hipSuccess)
+            return cleanup(fail(RT_ERR_HIP, "hipEventCreate failed"));
+    }
+    *out = s;
+    return RT_OK;
+}
+
+void rt_scene_destroy(rt_scene* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : s->allocations) (void)hipFree(p);
+    if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    if (s->d_rays) (void)hipFree(s->d_rays);
+    for (int i = 0; i < TIMING_RING; ++i) {
+        if (s->ev_start[i]) (void)hipEventDestroy(s->ev_start[i]);
+        if (s->ev_stop[i]) (void)hipEventDestroy(s->ev_stop[i]);
+    }
+    delete s;
+}
+
+int64_t rt_local_rows(int32_t height, const rt_params* p) {
+    if (check_params(p) != RT_OK || height < 0) return -1;
+    int ltr = local_tile_rows(height, p);
+    if (ltr == 0) return 0;
+    // every local tile is full except possibly the one that holds the frame's last rows
+    int64_t rows = (int64_t)ltr * RT_TILE;
+    int last_global_tile = (ltr - 1) * p->world_size + p->rank;
+    int64_t end = (int64_t)(last_global_tile + 1) * RT_TILE;
+    if (end > height) rows -= end - height;
+    return rows;
+}
+
+int64_t rt_global_row(int64_t local_row, const rt_params* p) {
+    if (check_params(p) != RT_OK || local_row < 0) return -1;
+    int64_t lt = local_row / RT_TILE;
+    return (lt * p->world_size + p->rank) * RT_TILE + local_row % RT_TILE;
+}
+
+int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* d_rgb, void* hip_stream) {
+    if (!s || !cam) return fail(RT_ERR_INVALID, "null scene or camera");
+    int rc = check_params(prm);
+    if (rc != RT_OK) return rc;
+    if (cam->width <= 0 || cam->height <= 0) return fail(RT_ERR_INVALID, "empty canvas");
+    HIP_TRY(hipSetDevice(s->device));
+    DevJob job{};
+    job.width = cam->width;
+    job.height = cam->height;
+    job.half_width = cam->half_width;
+    job.half_height = cam->half_height;
+    job.pixel_size = cam->pixel_size;
+    std::memcpy(job.inv, cam->inv, sizeof job.inv);
+    job.rank = prm->rank;
+    job.world_size = prm->world_size;
+    job.tiles_x = (cam->width + RT_TILE - 1) / RT_TILE;
+    job.local_tile_rows = local_tile_rows(cam->height, prm);
+    job.max_depth = prm->max_depth;
+    job.n_rays = 0;
+    long long tiles = (long long)job.tiles_x * job.local_tile_rows;
+    if (tiles > 0 && !d_rgb) return fail(RT_ERR_INVALID, "null output buffer");
+    long long blocks = (tiles + 3) / 4;
+    if (blocks > 0x7fffffffLL) return fail(RT_ERR_LIMIT, "frame too large for one launch");
+    return launch(s, job, (unsigned)blocks, d_rgb, (hipStream_t)hip_stream);
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* rgb_out, rt_stats* stats) {
+    if (!s || !cam) return fail(RT_ERR_INVALID, "null scene or camera");
+    int rc = check_params(prm);
+    if (rc != RT_OK) return rc;
+    int64_t rows = rt_local_rows(cam->height, prm);
+    size_t bytes = (size_t)rows * (size_t)cam->width * 3 * sizeof(double);
+    if (bytes && !rgb_out) return fail(RT_ERR_INVALID, "null output buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    if (bytes > s->frame_bytes) {
+        if (s->d_frame) HIP_TRY(hipFree(s->d_frame));
+        s->d_frame = nullptr;
+        s->frame_bytes = 0;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes));
+        s->d_frame = (double*)p;
+        s->frame_bytes = bytes;
+    }
+    rc = rt_render_device(s, cam, prm, s->d_frame, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    if (bytes) HIP_TRY(hipMemcpy(rgb_out, s->d_frame, bytes, hipMemcpyDeviceToHost));
+    return fill_stats(s, stats);
+}
+
+int rt_color_at(rt_scene* s, int64_t n, const double* origins, const double* directions, int32_t remaining,
+                double* rgb_out, rt_stats* stats) {
+    if (!s) return fail(RT_ERR_INVALID, "null scene");
+    if (n < 0) return fail(RT_ERR_INVALID, "negative ray count");
+    if (remaining < 0 || remaining > RT_MAX_DEPTH) return fail(RT_ERR_LIMIT, "remaining outside 0..RT_MAX_DEPTH");
+    if (n == 0) return RT_OK;
+    if (!origins || !directions || !rgb_out) return fail(RT_ERR_INVALID, "null ray or output buffer");
+    HIP_TRY(hipSetDevice(s->device));
+    size_t bytes = (size_t)n * 3 * sizeof(double);
+    if (3 * bytes > s->rays_bytes) {
+        if (s->d_rays) HIP_TRY(hipFree(s->d_rays));
+        s->d_rays = nullptr;
+        s->rays_bytes = 0;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, 3 * bytes));
+        s->d_rays = (double*)p;
+        s->rays_bytes = 3 * bytes;
+    }
+    double* d_o = s->d_rays;
+    double* d_d = s->d_rays + (size_t)n * 3;
+    double* d_c = s->d_rays + (size_t)n * 6;
+    HIP_TRY(hipMemcpy(d_o, origins, bytes, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_d, directions, bytes, hipMemcpyHostToDevice));
+    DevJob job{};
+    job.max_depth = remaining;
+    job.n_rays = n;
+    job.ray_o = d_o;
+    job.ray_d = d_d;
+    job.world_size = 1;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 0x7fffffffLL) return fail(RT_ERR_LIMIT, "too many rays for one launch");
+    int rc = launch(s, job, (unsigned)blocks, d_c, nullptr);
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(nullptr));
+    HIP_TRY(hipMemcpy(rgb_out, d_c, bytes, hipMemcpyDeviceToHost));
+    return fill_stats(s, stats);
+}
+
+int rt_scene_launch_times(rt_scene* s, float* ms, int cap) {
+    if (!s || !ms || cap < 0) return fail(RT_ERR_INVALID, "bad arguments");
+    long long have = s->launches < TIMING_RING ? s->launches : TIMING_RING;
+    if (have > cap) have = cap;
+    for (long long k = 0; k < have; ++k) {
+        long long idx = s->launches - have + k;
+        int slot = (int)(idx % TIMING_RING);
+        HIP_TRY(hipEventSynchronize(s->ev_stop[slot]));
+        HIP_TRY(hipEventElapsedTime(&ms[k], s->ev_start[slot], s->ev_stop[slot]));
+    }
+    return (int)have;
+}
+
+int rt_scene_ray_counts(rt_scene* s, rt_stats* st) {
+    if (!s || !st) return fail(RT_ERR_INVALID, "bad arguments");
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->last_stream));
+    return fill_stats(s, st);
+}
+
+}  // extern "C"
