@@ -1,0 +1,225 @@
+"""Benchmark of the render path: Mrays/s (primary + secondary) and frame time.
+
+  python bench.py --gpus 1 --steps K --warmup W            single GPU, default scene at 3840x2160
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+                                                          N GPUs, default scene at 7680x4320, the
+                                                          frame split into cyclic 8-row tiles and
+                                                          gathered to rank 0 over RCCL
+
+A step renders one frame from tables already resident in HBM into HBM (at N > 1 it also gathers the
+ranks' tiles into rank 0's full frame).  Rank 0 prints ONE JSON line.
+
+`roofline` prices the render kernel against the FP64 vector peak: achieved = algorithmic f64
+operations of the frame (counted by the CPU oracle, profiles/work_*.json; constants in DESIGN.md)
+/ the kernel's mean device time from HIP events on its launch stream.
+`cpu_baseline` times the CPU restatement of the reference in its cost-faithful mode (inverse
+recomputed per use, secondary rays re-traced per light, 12 worker threads like src/lib.rs:23) on a
+bounded sample of rows of the same frame, on this machine's host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 128 FLOP/clk x 2.4 GHz, FMA counted as 2 (datasheet)
+HBM_PEAK_GBS = 8000.0
+
+
+def load_work(name, W, H):
+    path = os.path.join(ROOT, "profiles", "work_%s_%dx%d.json" % (name, W, H))
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
+
+
+def cpu_baseline(name, W, H, budget_s=15.0):
+    """Cost-faithful CPU restatement on evenly spaced 2-row bands of the same frame."""
+    from oracle import binding
+    from raytracer_amd import scenes
+    orc = binding.load()
+    mw, mc = scenes.WORKLOADS[name]
+    world, cam = mw(orc), mc(orc, W, H)
+    threads = 12  # NUM_OF_THREADS, src/lib.rs:23
+    band = 2
+    n_bands = 24
+    starts = [int((k + 0.5) * H / n_bands) // band * band for k in range(n_bands)]
+    rays = 0
+    seconds = 0.0
+    rows = 0
+    for r0 in starts:
+        r1 = min(r0 + band, H)
+        orc.set_faithful(False)
+        _, cnt = orc.render(world, cam, threads=threads, rows=(r0, r1), counters=True)
+        orc.set_faithful(True)
+        t = time.perf_counter()
+        orc.render(world, cam, threads=threads, rows=(r0, r1))
+        seconds += time.perf_counter() - t
+        rays += cnt["rays_primary"] + cnt["rays_shadow"] + cnt["rays_reflect"] + cnt["rays_refract"]
+        rows += r1 - r0
+        if seconds > budget_s:
+            break
+    orc.set_faithful(False)
+    orc.reset()
+    return {
+        "value": rays / seconds / 1e6,
+        "unit": "Mrays/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d rows (%d evenly spaced bands of %d) of the %dx%d %s frame, %.1f s; rays counted "
+                  "once per hit as on the GPU, timed in the cost-faithful mode" % (rows, len(starts), band, W, H, name, seconds),
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="default")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from raytracer_amd import abi, api, scenes
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world_size != args.gpus:
+        raise SystemExit("--gpus %d needs a torch.distributed launch with WORLD_SIZE=%d" % (args.gpus, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # N = 1: the single-GPU configuration (3840x2160); N > 1: the 8K frame split across ranks.
+    W = args.width or (3840 if world_size == 1 else 7680)
+    H = args.height or (2160 if world_size == 1 else 4320)
+
+    host = api.load()
+    make_world, make_camera = scenes.WORKLOADS[args.workload]
+    world, cam = make_world(host), make_camera(host, W, H)
+    scene = host.scene_handle(world, device=local_rank)
+    rows = host.local_rows(H, rank, world_size)
+    local = torch.empty((rows, W, 3), dtype=torch.float64, device=dev)
+
+    frame = None
+    gather_list = None
+    row_index = None
+    if world_size > 1:
+        if rank == 0:
+            frame = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
+            gather_list = [torch.empty((host.local_rows(H, r, world_size), W, 3), dtype=torch.float64, device=dev)
+                           for r in range(world_size)]
+            row_index = [torch.from_numpy(host.global_rows(H, r, world_size)).to(dev) for r in range(world_size)]
+
+    def step():
+        stream = torch.cuda.current_stream().cuda_stream
+        host.render_device(world, cam, local.data_ptr(), stream=stream, device=local_rank, rank=rank,
+                           world_size=world_size)
+        if world_size > 1:
+            # Rooted gather of the compact per-rank tile buffers (sizes differ by at most one tile),
+            # then rank 0 scatters rows into frame order.
+            if rank == 0:
+                ops = [dist.P2POp(dist.irecv, gather_list[r], r) for r in range(1, world_size)]
+            else:
+                ops = [dist.P2POp(dist.isend, local, 0)]
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if rank == 0:
+                frame.index_copy_(0, row_index[0], local)
+                for r in range(1, world_size):
+                    frame.index_copy_(0, row_index[r], gather_list[r])
+
+    def sync():
+        if world_size > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    sync()
+    elapsed = time.perf_counter() - t0
+
+    # kernel device times of the timed launches, from HIP events on the launch stream
+    cap = min(args.steps, 256)
+    ms = (ctypes.c_float * cap)()
+    got = host.abi.rt_scene_launch_times(scene, ms, cap)
+    kernel_ms = sum(ms[i] for i in range(got)) / max(got, 1)
+    st = abi.rt_stats()
+    host.abi.rt_scene_ray_counts(scene, ctypes.byref(st))
+    rays_local = st.total_rays()
+
+    t = torch.tensor([elapsed, kernel_ms, float(rays_local)], dtype=torch.float64, device=dev)
+    if world_size > 1:
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        tsum = t.clone()
+        dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms, rays = float(tmax[0]), float(tmax[1]), float(tsum[2])
+    else:
+        rays = float(rays_local)
+
+    if rank == 0:
+        work = load_work(args.workload, W, H)
+        ms_per_step = elapsed / args.steps * 1e3
+        out = {
+            "metric": "Mrays/s (primary+secondary), %s scene %dx%d" % (args.workload, W, H),
+            "value": rays * args.steps / elapsed / 1e6,
+            "unit": "Mrays/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong" if world_size > 1 else "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s scene (src/lib.rs build_world), %dx%d, depth 5" % (args.workload, W, H),
+                "rays_per_frame": int(rays),
+                "partition": "cyclic 8-row tiles over %d rank(s)%s" % (world_size, ", RCCL gather to rank 0" if world_size > 1 else ""),
+            },
+            "kernel_ms": kernel_ms,
+        }
+        if work is not None:
+            flops = float(work["flops"])
+            achieved = flops / world_size / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+            out["roofline"] = {
+                "bound": "valu-fp64",
+                "achieved": achieved,
+                "peak": FP64_VECTOR_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+                "traffic": None,
+                "peak_without_fma": FP64_VECTOR_PEAK_TFLOPS / 2,
+                "frac_without_fma": achieved / (FP64_VECTOR_PEAK_TFLOPS / 2),
+                "algorithmic_flops_per_launch": flops / world_size,
+                "oracle_rays_per_frame": work["rays"],
+            }
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload, W, H)
+        print(json.dumps(out))
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -47,6 +47,10 @@ struct Counters {
     uint64_t aabb_test = 0, sphere_test = 0, plane_test = 0, cube_test = 0, cyl_test = 0,
              cone_test = 0, tri_test = 0, ray_xform = 0, shaded_hits = 0, light_evals = 0,
              pattern_nodes = 0, inverses = 0;
+    // Algorithmic f64 operations of the deduplicated path (one per add/sub/mul/div/sqrt/min/max/
+    // abs/compare/pow/cos on 3-component vectors and 3x4 affine matrices), accumulated with the
+    // per-event constants documented in DESIGN.md; and the non-identity ray transforms.
+    uint64_t flops = 0, xform_nonident = 0;
     void add(const Counters& o) {
         const uint64_t* s = reinterpret_cast<const uint64_t*>(&o);
         uint64_t* d = reinterpret_cast<uint64_t*>(this);
@@ -303,7 +307,14 @@ struct Xform {
     M4 fwd;
     M4 inv_cached;
     bool invertible;
-    explicit Xform(const M4& f) : fwd(f) { invertible = inverse_fast(f, inv_cached); }
+    bool ident;
+    explicit Xform(const M4& f) : fwd(f) {
+        invertible = inverse_fast(f, inv_cached);
+        ident = true;
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j)
+                if (f.m[i][j] != (i == j ? 1.0 : 0.0)) ident = false;
+    }
     M4 inv() const {
         if (g_faithful) {
             ++g_cnt.inverses;
@@ -404,6 +415,7 @@ inline void check_axis(double origin, double direction, double mn, double mx, do
 // bounding_box.rs:80-98
 bool bbox_intersects(const BBox& b, const Ray& r) {
     ++g_cnt.aabb_test;
+    g_cnt.flops += 26;
     double x0, x1, y0, y1, z0, z1;
     check_axis(r.o.x, r.d.x, b.mn.x, b.mx.x, x0, x1);
     check_axis(r.o.y, r.d.y, b.mn.y, b.mx.y, y0, y1);
@@ -506,6 +518,8 @@ struct Pattern {
     // pattern.rs:16-22
     Color local_pattern_at(Tuple object_point) const {
         ++g_cnt.pattern_nodes;
+        static const int extra[8] = {0, 2, 12, 6, 6, 6, 110, 0};
+        g_cnt.flops += (xf.ident ? 0 : 18) + extra[kind];
         Tuple pp = mul(xf.inv(), object_point);
         return pattern_at(pp);
     }
@@ -602,6 +616,10 @@ struct Shape {
     void intersect(const Ray& ray, std::vector<Hit>& out) const {
         M4 inv = xf.inv();
         ++g_cnt.ray_xform;
+        if (!xf.ident) {
+            ++g_cnt.xform_nonident;
+            g_cnt.flops += 33;
+        }
         Ray local = xform_ray(ray, inv);
         local_intersect(local, out);
     }
@@ -626,7 +644,9 @@ struct Shape {
                 double b = 2.0 * dot(r.d, sphere_to_ray);
                 double c = dot(sphere_to_ray, sphere_to_ray) - 1.0;
                 double disc = (b * b) - (4.0 * a * c);
+                g_cnt.flops += 24;
                 if (disc < 0.0) return;
+                g_cnt.flops += 10;
                 double t1 = (-b + std::sqrt(disc)) / (a * 2.0);
                 double t2 = (-b - std::sqrt(disc)) / (a * 2.0);
                 if (t1 < t2) {
@@ -640,12 +660,14 @@ struct Shape {
             }
             case S_PLANE: {  // plane.rs:51-74
                 ++g_cnt.plane_test;
+                g_cnt.flops += 4;
                 if (std::fabs(r.d.y) < EPSILON) return;
                 out.push_back({-r.o.y / r.d.y, this, 0, 0});
                 return;
             }
             case S_CUBE: {  // cube.rs:77-98
                 ++g_cnt.cube_test;
+                g_cnt.flops += 26;
                 double x0, x1, y0, y1, z0, z1;
                 check_axis(r.o.x, r.d.x, -1.0, 1.0, x0, x1);
                 check_axis(r.o.y, r.d.y, -1.0, 1.0, y0, y1);
@@ -660,6 +682,7 @@ struct Shape {
             case S_CYLINDER: {  // cylinder.rs:103-153
                 ++g_cnt.cyl_test;
                 double a = r.d.x * r.d.x + r.d.z * r.d.z;
+                g_cnt.flops += (a < EPSILON) ? 4 : 32;
                 if (a < EPSILON) {
                     caps(r, out, false);
                     return;
@@ -685,6 +708,7 @@ struct Shape {
                 double a = (r.d.x * r.d.x) - (r.d.y * r.d.y) + (r.d.z * r.d.z);
                 double b = (2.0 * r.o.x * r.d.x) - (2.0 * r.o.y * r.d.y) + (2.0 * r.o.z * r.d.z);
                 double c = (r.o.x * r.o.x) - (r.o.y * r.o.y) + (r.o.z * r.o.z);
+                g_cnt.flops += (std::fabs(a) < EPSILON) ? 24 : 40;
                 if (std::fabs(a) < EPSILON) {
                     if (std::fabs(b) < EPSILON) return;
                     double t = -c / (2.0 * b);
@@ -711,15 +735,19 @@ struct Shape {
                 ++g_cnt.tri_test;
                 Tuple dir_cross_e2 = cross(r.d, e2);
                 double det = dot(e1, dir_cross_e2);
+                g_cnt.flops += 16;
                 if (std::fabs(det) < EPSILON) return;
                 double f = 1.0 / det;
                 Tuple p1_to_origin = r.o - p1;
                 double u = f * dot(p1_to_origin, dir_cross_e2);
+                g_cnt.flops += 12;
                 if (u < 0.0 || u > 1.0) return;
                 Tuple origin_cross_e1 = cross(p1_to_origin, e1);
                 double v = f * dot(r.d, origin_cross_e1);
+                g_cnt.flops += 18;
                 if (v < 0.0 || (u + v) > 1.0) return;
                 double t = f * dot(e2, origin_cross_e1);
+                g_cnt.flops += 6;
                 if (kind == S_SMOOTH)
                     out.push_back({t, this, u, v});
                 else
@@ -732,6 +760,7 @@ struct Shape {
     // cylinder.rs:62-95 / cone.rs:63-96 (cone caps compare against |y|, not y*y)
     void caps(const Ray& r, std::vector<Hit>& out, bool cone) const {
         if (!closed || std::fabs(r.d.y) < EPSILON) return;
+        g_cnt.flops += 22;
         double t0 = (minimum - r.o.y) / r.d.y;
         if (cap_ok(r, t0, cone ? std::fabs(minimum) : 1.0)) out.push_back({t0, this, 0, 0});
         double t1 = (maximum - r.o.y) / r.d.y;
@@ -870,6 +899,10 @@ struct Shape {
 Color Material::lighting(const Shape* object, const Light& light, Tuple world_point, Tuple eyev,
                          Tuple normalv, bool in_shadow) const {
     ++g_cnt.light_evals;
+    g_cnt.flops += in_shadow ? 30 : 75;
+    if (pattern->kind != P_SOLID)
+        for (const Shape* s = object; s; s = s->parent)
+            if (!s->xf.ident) g_cnt.flops += 18;
     Tuple object_point = object->world_to_object(world_point);  // pattern.rs:8-14
     Color color = pattern->local_pattern_at(object_point);
     Color effective = color * light.intensity;
@@ -927,6 +960,13 @@ struct World {
     static Comps prepare(int hit_idx, const Ray& ray, const std::vector<Hit>& xs) {
         ++g_cnt.shaded_hits;
         const Hit& h = xs[hit_idx];
+        {
+            static const int normal_cost[8] = {0, 3, 15, 8, 8, 8, 0, 17};
+            uint64_t f = 60 + normal_cost[h.obj->kind];
+            for (const Shape* s = h.obj; s; s = s->parent) f += 9 + (s->xf.ident ? 0 : 33);
+            if (h.obj->material->transparency != 0.0) f += 2 * uint64_t(hit_idx + 1);
+            g_cnt.flops += f;
+        }
         Comps c;
         c.t = h.t;
         c.object = h.obj;
@@ -962,6 +1002,7 @@ struct World {
     // world.rs:304-326
     bool is_shadowed(Tuple p, const Light& light) const {
         ++g_cnt.rays_shadow;
+        g_cnt.flops += 20;
         Tuple v = light.position - p;
         double distance = magnitude(v);
         Tuple direction = normalize(v);
@@ -998,6 +1039,7 @@ struct World {
         double reflective = c.object->material->reflective;
         if (std::fabs(reflective - 0.0) < EPSILON) return BLACK;
         ++g_cnt.rays_reflect;
+        g_cnt.flops += 6;
         Ray r{c.over_point, c.reflectv};
         return color_at(r, remaining - 1) * reflective;
     }
@@ -1009,6 +1051,7 @@ struct World {
         double n_ratio = c.n1 / c.n2;
         double cos_i = dot(c.eyev, c.normalv);
         double sin2_t = (n_ratio * n_ratio) * (1.0 - (cos_i * cos_i));
+        g_cnt.flops += 32;
         if (sin2_t > 1.0) return BLACK;
         double cos_t = std::sqrt(1.0 - sin2_t);
         Tuple direction = c.normalv * (n_ratio * cos_i - cos_t) - c.eyev * n_ratio;
@@ -1032,9 +1075,11 @@ struct World {
                 have = true;
             }
             if (m.reflective > 0.0 && m.transparency > 0.0) {
+                g_cnt.flops += 18 + ((g_faithful || i == 0) ? 22 : 0);
                 double reflectance = schlick(c);
                 result = result + surface + (reflected * reflectance) + (refracted * (1.0 - reflectance));
             } else {
+                g_cnt.flops += 12;
                 result = result + surface + reflected + refracted;
             }
         }
@@ -1702,6 +1747,7 @@ void orc_render_rows(int64_t w, int64_t c, int remaining, int64_t row0, int64_t 
                 int64_t x = i % W, y = i / W;
                 Ray r = cam->ray_for_pixel((size_t)x, (size_t)y);
                 ++g_cnt.rays_primary;
+                g_cnt.flops += 36;
                 Color col = world->color_at(r, remaining);
                 rgb[i * 3] = col.r;
                 rgb[i * 3 + 1] = col.g;
