@@ -162,6 +162,13 @@ int rt_scene_launch_times(rt_scene* scene, float* ms, int cap);
 /* Ray counters of the most recent launch (synchronises the launch's stream). */
 int rt_scene_ray_counts(rt_scene* scene, rt_stats* stats);
 
+/* Device self-test with no counterpart in the reference: the kernel divides by a ray direction
+ * through its precomputed reciprocal (one exact correction step) instead of a full division per
+ * box plane.  This entry evaluates both forms on the device for n host-supplied pairs so a test
+ * can assert they agree bit for bit: out_fast[i] = corrected a[i] * (1/d[i]), out_ieee[i] = a[i]/d[i]. */
+int rt_selftest_division(int device, int64_t n, const double* a, const double* d, double* out_fast,
+                         double* out_ieee);
+
 const char* rt_last_error(void);
 
 #ifdef __cplusplus

@@ -100,6 +100,8 @@ SYMBOLS = {
                               C.POINTER(rt_stats)]),
     "rt_scene_launch_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "rt_scene_ray_counts": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
+    "rt_selftest_division": (C.c_int, [C.c_int, C.c_int64, C.POINTER(c_d), C.POINTER(c_d), C.POINTER(c_d),
+                                       C.POINTER(c_d)]),
     "rt_last_error": (C.c_char_p, []),
 }
 

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -38,7 +39,25 @@
 
 namespace {
 
+// Traversal record: everything one step of the scene walk needs, in one 128-byte line, so that a
+// step costs a single scalar-load round trip.  Records follow the pre-order of the node table; a
+// node whose transform is not the identity AND which carries its own payload (a transformed group
+// or triangle) is preceded by an extra T_XFORM record that holds its inverse.
+enum { T_XFORM = 8, T_HAS_INV = 0x100, T_CLOSED = 0x200, T_OWN_XFORM = 0x400 };
+struct alignas(16) TRec {
+    int kind;    // low byte: RT_* type or T_XFORM; T_HAS_INV: p holds rows 0..2 of the inverse; T_CLOSED;
+                 // T_OWN_XFORM: the record before this one is this node's T_XFORM record
+    int skip;    // first record after this node's subtree
+    int ctx;     // record holding the inverse of the nearest enclosing transformed group, or -1
+    int node;    // index into the node table (what a hit reports)
+    double r0, r1;  // cylinder / cone minimum, maximum
+    double p[12];   // inverse rows | group bounds (6) | triangle p1, e1, e2 (9)
+};
+static_assert(sizeof(TRec) == 128, "traversal record must be 128 bytes");
+
 struct DevScene {
+    const RT_CONST TRec* trav;
+    int n_trav;
     const RT_CONST rt_node* nodes;
     const RT_CONST rt_xform* xforms;
     const RT_CONST rt_aabb* aabbs;
@@ -52,6 +71,7 @@ struct DevScene {
     int n_nodes;
     int n_lights;
     int all_cast_shadow;
+    int finite_bounds;  // every group box is finite (no plane inside a group)
 };
 
 struct DevJob {
@@ -62,6 +82,7 @@ struct DevJob {
     // partition
     int rank, world_size, tiles_x, local_tile_rows;
     int max_depth;
+    int xcd_remap;
     // ray-list mode (rt_color_at)
     long long n_rays;
     const double* ray_o;
@@ -126,13 +147,16 @@ DI V3 chain_point(const DevScene& S, int ctx, V3 p) {
         if (c[k] >= 0) p = xpoint(S.xforms[S.nodes[c[k]].xform].inv, p);
     return p;
 }
+// The same for a ray during traversal, on the traversal records (`ctx` is a record index there).
 DI void chain_ray(const DevScene& S, int ctx, V3& o, V3& d) {
     int c[RT_MAX_XFORM_NEST];
-    chain_collect(S, ctx, c);
+    c[0] = ctx;
+#pragma unroll
+    for (int k = 1; k < RT_MAX_XFORM_NEST; ++k) c[k] = c[k - 1] >= 0 ? S.trav[c[k - 1]].ctx : -1;
 #pragma unroll
     for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
         if (c[k] >= 0) {
-            const RT_CONST double* m = S.xforms[S.nodes[c[k]].xform].inv;
+            const RT_CONST double* m = S.trav[c[k]].p;
             o = xpoint(m, o);
             d = xvec(m, d);
         }
@@ -159,6 +183,30 @@ DI void slabs(V3 o, V3 d, double x0, double y0, double z0, double x1, double y1,
     tmin = fmax(fmax(xa, ya), za);
     tmax = fmin(fmin(xb, yb), zb);
 }
+
+// Exact division by a value whose correctly rounded reciprocal y = 1.0 / d is already known:
+// q0 = a*y is within 2 ulp of a/d, r = a - q0*d is exact in an FMA, and rounding q0 + r*y once
+// gives the correctly rounded quotient -- the same final step the hardware's own f64 division
+// expansion ends with.  It returns the IEEE quotient bit for bit for finite a and normal d, q
+// (rt_selftest_division checks this on the device); it is NOT valid for infinite a.
+DI double div_by(double a, double d, double y) {
+    double q0 = a * y;
+    double r = __builtin_fma(-q0, d, a);
+    return __builtin_fma(r, y, q0);
+}
+// The slab test for lanes whose direction components all satisfy |d| >= RT_EPS and whose box is
+// finite: the `* INFINITY` branch of check_axis is not taken and no NaN can arise, so the ordered
+// pair is (min, max) of the two quotients.
+DI void slabs_fast(V3 o, V3 d, V3 y, double x0, double y0, double z0, double x1, double y1, double z1,
+                   double& tmin, double& tmax) {
+    double ax = div_by(x0 - o.x, d.x, y.x), bx = div_by(x1 - o.x, d.x, y.x);
+    double ay = div_by(y0 - o.y, d.y, y.y), by = div_by(y1 - o.y, d.y, y.y);
+    double az = div_by(z0 - o.z, d.z, y.z), bz = div_by(z1 - o.z, d.z, y.z);
+    tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+    tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+}
+DI bool all_axes_finite(V3 d) { return fabs(d.x) >= RT_EPS && fabs(d.y) >= RT_EPS && fabs(d.z) >= RT_EPS; }
+DI V3 reciprocal(V3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
 
 // Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
 // for the n1/n2 bookkeeping, the parity and the latest of the leaf's non-positive times.
@@ -226,50 +274,69 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     if (__ballot(active) == 0ull) return;
 
     int skip_until = active ? 0 : INT_MAX;
-    const int n = S.n_nodes;
+    const int n = S.n_trav;
     int i = 0;
     int cur_ctx = -1;
-    V3 co = wo, cd = wd;  // the ray in the space of group `cur_ctx`
+    V3 co = wo, cd = wd;  // the ray in the space of the transformed group `cur_ctx`
+    V3 cy = reciprocal(cd);  // exact reciprocals of cd, used by the fast slab test
+    bool cfin = all_axes_finite(cd);
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
 
     while (i < n) {
         i = __builtin_amdgcn_readfirstlane(i);
-        const int type = S.nodes[i].type;
-        const int xf = S.nodes[i].xform;
-        const int data = S.nodes[i].data;
-        const int skip = S.nodes[i].skip;
-        const int ctx = S.nodes[i].ctx;
+        const RT_CONST TRec* rec = S.trav + i;
+        // Fetch the whole 128-byte record with one scalar-load round trip.  The empty asm
+        // statements make every field live here, so the loads are issued together instead of
+        // one dependent load per use.
+        const int kind = rec->kind;
+        const int skip = rec->skip;
+        const int ctx = rec->ctx;
+        const int rnode = rec->node;
+        const double r0 = rec->r0, r1 = rec->r1;
+        double q[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) q[k] = rec->p[k];
+        asm volatile("" ::"s"(kind), "s"(skip), "s"(ctx), "s"(rnode), "s"(r0), "s"(r1));
+        asm volatile("" ::"s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]),
+                     "s"(q[8]), "s"(q[9]), "s"(q[10]), "s"(q[11]));
+        const int type = kind & 0xff;
         if (ctx != cur_ctx) {
             co = wo;
             cd = wd;
             chain_ray(S, ctx, co, cd);
+            cy = reciprocal(cd);
+            cfin = all_axes_finite(cd);
             cur_ctx = ctx;
         }
         const bool act = i >= skip_until;
-        V3 lo = co, ld = cd;
-        if (xf >= 0) {  // Shape::intersect: world_ray.transform(inverse) (shape.rs:24-26, ray.rs:30-35)
-            const RT_CONST double* m = S.xforms[xf].inv;
-            lo = xpoint(m, co);
-            ld = xvec(m, cd);
+        if (type == T_XFORM) {
+            // The inverse of a transformed group (or triangle): the records after it, up to the
+            // end of the node's subtree, see the ray in that node's space.
+            V3 to = xpoint(q, co), td = xvec(q, cd);
+            co = to;
+            cd = td;
+            cy = reciprocal(cd);
+            cfin = all_axes_finite(cd);
+            cur_ctx = i;
+            i = i + 1;
+            continue;
         }
         if (type == RT_GROUP) {
             // Group::local_intersect (group.rs:133-154): bounds test in the group's own space.
-            const RT_CONST rt_aabb* bb = S.aabbs + data;
             double tmin, tmax;
-            slabs(lo, ld, bb->min[0], bb->min[1], bb->min[2], bb->max[0], bb->max[1], bb->max[2], tmin, tmax);
+            if (S.finite_bounds && __ballot(act && !cfin) == 0ull)
+                slabs_fast(co, cd, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
+            else
+                slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
             bool inside = act && !(tmin > tmax);
             if (act && !inside) skip_until = skip;
-            if (__ballot(inside) == 0ull) {
-                i = skip;
-            } else {
-                if (xf >= 0) {
-                    co = lo;
-                    cd = ld;
-                    cur_ctx = i;
-                }
-                i = i + 1;
-            }
+            i = (__ballot(inside) == 0ull) ? skip : i + 1;
             continue;
+        }
+        V3 lo = co, ld = cd;
+        if (kind & T_HAS_INV) {  // Shape::intersect: world_ray.transform(inverse) (shape.rs:24-26, ray.rs:30-35)
+            lo = xpoint(q, co);
+            ld = xvec(q, cd);
         }
 
         LeafAcc acc;
@@ -299,7 +366,10 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 }
                 case RT_CUBE: {  // cube.rs:77-98
                     double tmin, tmax;
-                    slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
+                    if (__ballot(!all_axes_finite(ld)) == 0ull)
+                        slabs_fast(lo, ld, reciprocal(ld), -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
+                    else
+                        slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
                     if (!(tmin > tmax)) {
                         leaf_add<TRACK>(acc, tmin);
                         leaf_add<TRACK>(acc, tmax);
@@ -309,9 +379,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 case RT_CYLINDER:
                 case RT_CONE: {  // cylinder.rs:62-153, cone.rs:63-163
                     const bool cone = type == RT_CONE;
-                    const double mn = S.ranges[data].minimum;
-                    const double mx = S.ranges[data].maximum;
-                    const bool closed = (S.nodes[i].flags & RT_NODE_CLOSED) != 0;
+                    const double mn = r0;
+                    const double mx = r1;
+                    const bool closed = (kind & T_CLOSED) != 0;
                     double a, b, c;
                     bool walls, done = false;
                     if (cone) {
@@ -365,10 +435,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     break;
                 }
                 default: {  // RT_TRIANGLE, RT_SMOOTH_TRIANGLE: triangle.rs:83-111, smooth_triangle.rs:101-129
-                    const RT_CONST rt_tri* tr = S.tris + data;
-                    V3 p1 = mk(tr->p1[0], tr->p1[1], tr->p1[2]);
-                    V3 e1 = mk(tr->e1[0], tr->e1[1], tr->e1[2]);
-                    V3 e2 = mk(tr->e2[0], tr->e2[1], tr->e2[2]);
+                    V3 p1 = mk(q[0], q[1], q[2]);
+                    V3 e1 = mk(q[3], q[4], q[5]);
+                    V3 e2 = mk(q[6], q[7], q[8]);
                     V3 dir_cross_e2 = cross(ld, e2);
                     double det = dot(e1, dir_cross_e2);
                     if (!(fabs(det) < RT_EPS)) {
@@ -394,7 +463,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             if (acc.found && (!h.found || acc.best < h.t)) {
                 h.found = true;
                 h.t = acc.best;
-                h.node = i;
+                h.node = rnode;
                 h.u = hu;
                 h.v = hv;
                 h.par = acc.par;
@@ -404,10 +473,10 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     h.b_t = h.a_t;
                     h.b_id = h.a_id;
                     h.a_t = acc.negmax;
-                    h.a_id = i;
+                    h.a_id = rnode;
                 } else if (h.b_id < 0 || acc.negmax >= h.b_t) {
                     h.b_t = acc.negmax;
-                    h.b_id = i;
+                    h.b_id = rnode;
                 }
             }
             if (early && h.found && h.t < limit) skip_until = INT_MAX;  // this lane is decided
@@ -591,8 +660,11 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
     return acc;
 }
 
+#ifndef RT_MIN_WAVES
+#define RT_MIN_WAVES 1
+#endif
 template <bool TRACK>
-__global__ void __launch_bounds__(256) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
+__global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -613,7 +685,7 @@ __global__ void __launch_bounds__(256) rt_kernel(DevScene S, DevJob J, double* _
         // contiguous band of tiles and its L2 sees a spatially coherent part of the scene.
         const unsigned nwg = gridDim.x;
         unsigned b = blockIdx.x;
-        {
+        if (J.xcd_remap) {
             unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
             b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
@@ -894,6 +966,17 @@ __global__ void __launch_bounds__(256) rt_kernel(DevScene S, DevJob J, double* _
     }
 }
 
+// Device self-test of div_by: out_fast[i] = div_by(a[i], d[i], 1.0 / d[i]), out_ieee[i] = a[i] / d[i].
+__global__ void division_selftest_kernel(long long n, const double* a, const double* d, double* out_fast,
+                                         double* out_ieee) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) {
+        double y = 1.0 / d[i];
+        out_fast[i] = div_by(a[i], d[i], y);
+        out_ieee[i] = a[i] / d[i];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Host side of the C ABI
 // ---------------------------------------------------------------------------------------------
@@ -1038,6 +1121,56 @@ int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
     return RT_OK;
 }
 
+// Lays the node table out as traversal records (see TRec).
+std::vector<TRec> build_records(const rt_scene_desc* d) {
+    std::vector<TRec> out;
+    std::vector<int> first(d->n_nodes + 1, 0);
+    // pass 1: record index of every node's first record
+    int count = 0;
+    for (int i = 0; i < d->n_nodes; ++i) {
+        const rt_node& n = d->nodes[i];
+        first[i] = count;
+        const bool own_payload = n.type == RT_GROUP || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
+        count += (n.xform >= 0 && own_payload) ? 2 : 1;
+    }
+    first[d->n_nodes] = count;
+    out.reserve(count);
+    for (int i = 0; i < d->n_nodes; ++i) {
+        const rt_node& n = d->nodes[i];
+        const bool own_payload = n.type == RT_GROUP || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
+        TRec r{};
+        r.skip = first[n.skip];
+        r.ctx = n.ctx >= 0 ? first[n.ctx] : -1;
+        r.node = i;
+        int flags = (n.flags & RT_NODE_CLOSED) ? T_CLOSED : 0;
+        if (n.xform >= 0 && own_payload) {
+            TRec x = r;
+            x.kind = T_XFORM | T_HAS_INV;
+            std::memcpy(x.p, d->xforms[n.xform].inv, sizeof x.p);
+            out.push_back(x);
+            flags |= T_OWN_XFORM;
+            r.ctx = first[i];  // the node itself is tested in its own space
+        } else if (n.xform >= 0) {
+            flags |= T_HAS_INV;
+            std::memcpy(r.p, d->xforms[n.xform].inv, sizeof r.p);
+        }
+        r.kind = n.type | flags;
+        if (n.type == RT_GROUP) {
+            std::memcpy(r.p, d->aabbs[n.data].min, 3 * sizeof(double));
+            std::memcpy(r.p + 3, d->aabbs[n.data].max, 3 * sizeof(double));
+        } else if (n.type == RT_CYLINDER || n.type == RT_CONE) {
+            r.r0 = d->ranges[n.data].minimum;
+            r.r1 = d->ranges[n.data].maximum;
+        } else if (n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE) {
+            std::memcpy(r.p, d->tris[n.data].p1, 3 * sizeof(double));
+            std::memcpy(r.p + 3, d->tris[n.data].e1, 3 * sizeof(double));
+            std::memcpy(r.p + 6, d->tris[n.data].e2, 3 * sizeof(double));
+        }
+        out.push_back(r);
+    }
+    return out;
+}
+
 int check_params(const rt_params* p) {
     if (!p) return fail(RT_ERR_INVALID, "null params");
     if (p->world_size < 1 || p->rank < 0 || p->rank >= p->world_size)
@@ -1120,6 +1253,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         rt_scene_destroy(s);
         return code;
     };
+    {
+        std::vector<TRec> recs = build_records(d);
+        if ((rc = upload(s, recs.data(), recs.size(), &s->dev.trav)) != RT_OK) return cleanup(rc);
+        s->dev.n_trav = (int)recs.size();
+    }
     if ((rc = upload(s, d->nodes, d->n_nodes, &s->dev.nodes)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->aabbs, d->n_aabbs, &s->dev.aabbs)) != RT_OK) return cleanup(rc);
@@ -1134,6 +1272,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->dev.n_nodes = d->n_nodes;
     s->dev.n_lights = d->n_lights;
     s->dev.all_cast_shadow = all_cast ? 1 : 0;
+    s->dev.finite_bounds = 1;
+    for (int i = 0; i < d->n_aabbs; ++i)
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(d->aabbs[i].min[k]) || !std::isfinite(d->aabbs[i].max[k])) s->dev.finite_bounds = 0;
     void* p = nullptr;
     if (hipMalloc(&p, 4 * sizeof(unsigned long long)) != hipSuccess)
         return cleanup(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
@@ -1197,6 +1339,10 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, do
     job.tiles_x = (cam->width + RT_TILE - 1) / RT_TILE;
     job.local_tile_rows = local_tile_rows(cam->height, prm);
     job.max_depth = prm->max_depth;
+    {
+        const char* e = getenv("RT_XCD_REMAP");
+        job.xcd_remap = e ? atoi(e) : 0;
+    }
     job.n_rays = 0;
     long long tiles = (long long)job.tiles_x * job.local_tile_rows;
     if (tiles > 0 && !d_rgb) return fail(RT_ERR_INVALID, "null output buffer");
@@ -1265,6 +1411,30 @@ int rt_color_at(rt_scene* s, int64_t n, const double* origins, const double* dir
     HIP_TRY(hipStreamSynchronize(nullptr));
     HIP_TRY(hipMemcpy(rgb_out, d_c, bytes, hipMemcpyDeviceToHost));
     return fill_stats(s, stats);
+}
+
+int rt_selftest_division(int device, int64_t n, const double* a, const double* d, double* out_fast,
+                         double* out_ieee) {
+    if (n < 0 || (n && (!a || !d || !out_fast || !out_ieee))) return fail(RT_ERR_INVALID, "bad arguments");
+    if (n == 0) return RT_OK;
+    HIP_TRY(hipSetDevice(device));
+    size_t bytes = (size_t)n * sizeof(double);
+    double* buf = nullptr;
+    HIP_TRY(hipMalloc((void**)&buf, 4 * bytes));
+    int rc = RT_OK;
+    if (hipMemcpy(buf, a, bytes, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemcpy(buf + n, d, bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(RT_ERR_HIP, "hipMemcpy to device failed");
+    } else {
+        hipLaunchKernelGGL(division_selftest_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr,
+                           (long long)n, buf, buf + n, buf + 2 * n, buf + 3 * n);
+        if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
+            hipMemcpy(out_fast, buf + 2 * n, bytes, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(out_ieee, buf + 3 * n, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(RT_ERR_HIP, "division self-test kernel failed");
+    }
+    (void)hipFree(buf);
+    return rc;
 }
 
 int rt_scene_launch_times(rt_scene* s, float* ms, int cap) {

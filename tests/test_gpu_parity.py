@@ -91,3 +91,30 @@ def test_color_at_batch(host, orc):
     got = host.color_at(mw(host), o, d, remaining=5)
     ref = orc.color_at_batch(mw(orc), o, d, remaining=5)
     assert np.abs(got - ref).max() <= 1e-11
+
+
+def test_division_by_reciprocal_is_exact(host):
+    """The kernel's a/d via the exact reciprocal of d must equal IEEE division bit for bit."""
+    import ctypes as C
+    rng = np.random.default_rng(11)
+    n = 4_000_000
+    # magnitudes as they occur (numerators up to scene size, |d| >= 1e-5) plus wide-exponent and
+    # near-power-of-two / all-ones-mantissa denominators
+    a = rng.uniform(-50, 50, n) * 10.0 ** rng.integers(-12, 6, n)
+    d = rng.uniform(1e-5, 2.0, n) * rng.choice([-1.0, 1.0], n)
+    k = n // 4
+    d[:k] = np.ldexp(1.0 + rng.integers(0, 8, k) * 2.0 ** -52, rng.integers(-16, 10, k))
+    d[k:2 * k] = np.ldexp(2.0 - rng.integers(1, 8, k) * 2.0 ** -52, rng.integers(-16, 10, k))
+    a[::7] = np.round(a[::7])          # exact-looking numerators
+    a[::11] = d[::11] * np.round(rng.uniform(-100, 100, a[::11].size))  # quotients near integers
+    a[0], a[1] = 0.0, -0.0
+    fast = np.empty(n)
+    ieee = np.empty(n)
+    P = C.POINTER(C.c_double)
+    rc = host.abi.rt_selftest_division(0, n, a.ctypes.data_as(P), d.ctypes.data_as(P), fast.ctypes.data_as(P),
+                                       ieee.ctypes.data_as(P))
+    assert rc == 0, host.abi.rt_last_error()
+    assert np.array_equal(ieee, a / d)          # the device's own division is IEEE
+    bad = np.flatnonzero(fast.view(np.uint64) != ieee.view(np.uint64))
+    bad = bad[~((fast[bad] == 0) & (ieee[bad] == 0))]  # signed zeros aside
+    assert bad.size == 0, (a[bad[:5]], d[bad[:5]], fast[bad[:5]], ieee[bad[:5]])
