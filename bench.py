@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-depth", type=int, default=5, help="diagnostic: `remaining` of primary rays (the metric uses 5)")
     args = ap.parse_args()
 
     import torch
@@ -128,7 +129,7 @@ def main():
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         host.render_device(world, cam, local.data_ptr(), stream=stream, device=local_rank, rank=rank,
-                           world_size=world_size)
+                           world_size=world_size, max_depth=args.max_depth)
         if world_size > 1:
             # Rooted gather of the compact per-rank tile buffers (sizes differ by at most one tile),
             # then rank 0 scatters rows into frame order.
@@ -177,7 +178,7 @@ def main():
         rays = float(rays_local)
 
     if rank == 0:
-        work = load_work(args.workload, W, H)
+        work = load_work(args.workload, W, H) if args.max_depth == 5 else None
         ms_per_step = elapsed / args.steps * 1e3
         out = {
             "metric": "Mrays/s (primary+secondary), %s scene %dx%d" % (args.workload, W, H),

@@ -36,6 +36,7 @@
 #define RT_EPS 0.00001  // src/lib.rs:22
 #define RT_MAX_FRAMES RT_MAX_DEPTH
 #define RT_PAT_STACK (RT_MAX_PATTERN_NEST + 1)
+#define COUNTER_SHARDS 1024u  // each shard is 16 u64 (one 128-byte line)
 
 namespace {
 
@@ -240,6 +241,9 @@ struct Hit {
     int par;
     double a_t, b_t;
     int a_id, b_id;
+#ifdef RT_PROFILE
+    int visits;  // records visited by the wavefront (diagnostic build only)
+#endif
 };
 
 DI int wave_min(int v) {
@@ -271,6 +275,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     h.b_t = 0.0;
     h.a_id = -1;
     h.b_id = -1;
+#ifdef RT_PROFILE
+    h.visits = 0;
+#endif
     if (__ballot(active) == 0ull) return;
 
     int skip_until = active ? 0 : INT_MAX;
@@ -282,8 +289,14 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     bool cfin = all_axes_finite(cd);
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
 
+#ifdef RT_PROFILE
+    h.visits = 0;
+#endif
     while (i < n) {
         i = __builtin_amdgcn_readfirstlane(i);
+#ifdef RT_PROFILE
+        ++h.visits;
+#endif
         const RT_CONST TRec* rec = S.trav + i;
         // Fetch the whole 128-byte record with one scalar-load round trip.  The empty asm
         // statements make every field live here, so the loads are issued together instead of
@@ -717,9 +730,22 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
     V3 final_colour = mk(0.0, 0.0, 0.0);
     const int L = S.n_lights;
 
+#ifdef RT_PROFILE
+    unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
+    unsigned long long prof_closest = 0, prof_shadow = 0, prof_visits = 0, prof_traces = 0, prof_rounds = 0;
+#endif
     while (__ballot(pending) != 0ull) {
         Hit h;
+#ifdef RT_PROFILE
+        unsigned long long pt = __builtin_amdgcn_s_memtime();
+#endif
         trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST>(S, pending, ro, rd, 0.0, h);
+#ifdef RT_PROFILE
+        prof_closest += __builtin_amdgcn_s_memtime() - pt;
+        prof_visits += h.visits;
+        prof_traces += 1;
+        prof_rounds += 1;
+#endif
         const bool shade = pending && h.found;
 
         // ---- World::prepare_computations (world.rs:70-147) --------------------------------
@@ -854,7 +880,15 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
             double distance = magnitude(lv);
             V3 lightv = lv / distance;
             Hit sh;
+#ifdef RT_PROFILE
+            unsigned long long ps = __builtin_amdgcn_s_memtime();
+#endif
             trace<MODE_SHADOW>(S, shade, over, lightv, distance, sh);
+#ifdef RT_PROFILE
+            prof_shadow += __builtin_amdgcn_s_memtime() - ps;
+            prof_visits += sh.visits;
+            prof_traces += (__ballot(shade) != 0ull) ? 1 : 0;
+#endif
             if (shade) {
                 ++n_shadow;
                 bool in_shadow = sh.found && sh.t < distance &&
@@ -955,7 +989,20 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
         out[out_index * 3 + 1] = final_colour.y;
         out[out_index * 3 + 2] = final_colour.z;
     }
-    // ray statistics: one atomic per wavefront and counter
+#ifdef RT_PROFILE
+    if (lane == 0) {
+        atomicAdd(&counters[4], __builtin_amdgcn_s_memtime() - prof_t0);
+        atomicAdd(&counters[5], prof_closest);
+        atomicAdd(&counters[6], prof_shadow);
+        atomicAdd(&counters[7], prof_visits);
+        atomicAdd(&counters[8], prof_traces);
+        atomicAdd(&counters[9], prof_rounds);
+        atomicAdd(&counters[10], 1ull);
+    }
+#endif
+    // Ray statistics: one atomic per wavefront and counter, spread over COUNTER_SHARDS copies so
+    // that the 10^5 wavefronts of a frame do not serialise on four words.
+    counters += 16 * ((blockIdx.x * 4u + (unsigned)wave) % COUNTER_SHARDS);
     unsigned c[4] = {n_primary, n_shadow, n_reflect, n_refract};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1188,7 +1235,7 @@ int local_tile_rows(int height, const rt_params* p) {
 
 int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipStream_t stream) {
     int slot = (int)(s->launches % TIMING_RING);
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, 4 * sizeof(unsigned long long), stream));
+    HIP_TRY(hipMemsetAsync(s->d_counters, 0, COUNTER_SHARDS * 16 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (blocks > 0) {
         if (s->any_transparent)
@@ -1207,14 +1254,24 @@ int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipSt
 
 int fill_stats(rt_scene* s, rt_stats* st) {
     if (!st) return RT_OK;
-    unsigned long long c[4];
-    HIP_TRY(hipMemcpy(c, s->d_counters, sizeof c, hipMemcpyDeviceToHost));
+    std::vector<unsigned long long> shards(COUNTER_SHARDS * 16);
+    HIP_TRY(hipMemcpy(shards.data(), s->d_counters, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    unsigned long long c[16] = {};
+    for (unsigned k = 0; k < COUNTER_SHARDS; ++k)
+        for (int j = 0; j < 16; ++j) c[j] += shards[k * 16 + j];
     st->rays_primary = c[0];
     st->rays_shadow = c[1];
     st->rays_reflect = c[2];
     st->rays_refract = c[3];
     st->kernel_ms = 0.0f;
     st->reserved = 0.0f;
+#ifdef RT_PROFILE
+    {
+        const unsigned long long* pc = c;
+        fprintf(stderr, "RT_PROFILE waves=%llu wave_cycles=%llu closest_cycles=%llu shadow_cycles=%llu visits=%llu traces=%llu rounds=%llu\n",
+                pc[10], pc[4], pc[5], pc[6], pc[7], pc[8], pc[9]);
+    }
+#endif
     if (s->launches > 0) {
         int slot = (int)((s->launches - 1) % TIMING_RING);
         HIP_TRY(hipEventSynchronize(s->ev_stop[slot]));
@@ -1277,7 +1334,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(d->aabbs[i].min[k]) || !std::isfinite(d->aabbs[i].max[k])) s->dev.finite_bounds = 0;
     void* p = nullptr;
-    if (hipMalloc(&p, 4 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&p, COUNTER_SHARDS * 16 * sizeof(unsigned long long)) != hipSuccess)
         return cleanup(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
     s->d_counters = (unsigned long long*)p;
     for (int i = 0; i < TIMING_RING; ++i) {
