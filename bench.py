@@ -116,33 +116,15 @@ def main():
     rows = host.local_rows(H, rank, world_size)
     local = torch.empty((rows, W, 3), dtype=torch.float64, device=dev)
 
-    frame = None
-    gather_list = None
-    row_index = None
-    if world_size > 1:
-        if rank == 0:
-            frame = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
-            gather_list = [torch.empty((host.local_rows(H, r, world_size), W, 3), dtype=torch.float64, device=dev)
-                           for r in range(world_size)]
-            row_index = [torch.from_numpy(host.global_rows(H, r, world_size)).to(dev) for r in range(world_size)]
+    from raytracer_amd.distributed import FrameGather
+    gather = FrameGather(host, W, H, rank, world_size, dev) if world_size > 1 else None
 
     def step():
         stream = torch.cuda.current_stream().cuda_stream
         host.render_device(world, cam, local.data_ptr(), stream=stream, device=local_rank, rank=rank,
                            world_size=world_size, max_depth=args.max_depth)
-        if world_size > 1:
-            # Rooted gather of the compact per-rank tile buffers (sizes differ by at most one tile),
-            # then rank 0 scatters rows into frame order.
-            if rank == 0:
-                ops = [dist.P2POp(dist.irecv, gather_list[r], r) for r in range(1, world_size)]
-            else:
-                ops = [dist.P2POp(dist.isend, local, 0)]
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if rank == 0:
-                frame.index_copy_(0, row_index[0], local)
-                for r in range(1, world_size):
-                    frame.index_copy_(0, row_index[r], gather_list[r])
+        if gather is not None:
+            gather(local)  # RCCL send/recv of the compact tile buffers to rank 0, rows into frame order
 
     def sync():
         if world_size > 1:

@@ -59,7 +59,7 @@ class OracleApi(Api):
             "ray_for_pixel": (None, [c_i64, c_i64, c_i64, c_dp, c_dp]),
             "world_intersect": (C.c_int, [c_i64, c_dp, c_dp, c_dp, c_ip, C.c_int]),
             "prepare": (C.c_int, [c_i64, c_dp, c_dp, c_dp]),
-            "comps_eval": (C.c_int, [c_i64, c_dp, c_dp, c_dp, c_ip, C.c_int, C.c_int, C.c_int,
+            "comps_eval": (C.c_int, [c_i64, c_dp, c_dp, c_dp, c_ip, c_dp, C.c_int, C.c_int, C.c_int,
                                      C.c_int, c_dp]),
             "color_at": (None, [c_i64, c_dp, c_dp, C.c_int, c_dp]),
             "color_at_batch": (None, [c_i64, c_i64, c_dp, c_dp, C.c_int, c_dp]),
@@ -146,16 +146,28 @@ class OracleApi(Api):
                     eyev=tuple(o[13:17]), normalv=tuple(o[17:21]), reflectv=tuple(o[21:25]), n1=o[25],
                     n2=o[26], inside=bool(o[27]), object=int(o[28]), schlick=o[29])
 
+    @staticmethod
+    def _comps_dict(o):
+        return dict(t=o[0], point=tuple(o[1:5]), over_point=tuple(o[5:9]), under_point=tuple(o[9:13]),
+                    eyev=tuple(o[13:17]), normalv=tuple(o[17:21]), reflectv=tuple(o[21:25]), n1=o[25],
+                    n2=o[26], inside=bool(o[27]), object=int(o[28]), schlick=o[29])
+
     def comps_eval(self, world, ray, xs, hit_index, which, remaining=5):
         """prepare_computations(hit_index, ray, xs) followed by shade_hit (0), reflected_color (1),
-        refracted_color (2) or (schlick, n1, n2) (3).  xs: list of (t, shape)."""
-        ts = _arr([t for t, _ in xs])
-        objs = (c_i64 * len(xs))(*[s.h for _, s in xs])
-        out = (c_d * 3)()
-        rc = self._f("comps_eval")(world.h, _arr(ray.origin), _arr(ray.direction), ts, objs, len(xs),
-                                   hit_index, which, remaining, out)
+        refracted_color (2), (schlick, n1, n2) (3) or the Computations as a dict (4).
+        xs: list of (t, shape) or (t, shape, u, v); world may be None for 3 and 4."""
+        ts = _arr([x[0] for x in xs])
+        objs = (c_i64 * len(xs))(*[x[1].h for x in xs])
+        uv = _arr([c for x in xs for c in (x[2:4] if len(x) == 4 else (0.0, 0.0))])
+        out = (c_d * 30)()
+        rc = self._f("comps_eval")(world.h if world is not None else -1, _arr(ray.origin),
+                                   _arr(ray.direction), ts, objs, uv, len(xs), hit_index, which, remaining,
+                                   out)
         assert rc == 0
-        return tuple(out)
+        return self._comps_dict(list(out)) if which == 4 else tuple(out[:3])
+
+    def prepare_computations(self, hit_index, ray, xs):
+        return self.comps_eval(None, ray, xs, hit_index, 4)
 
     def color_at(self, world, ray, remaining=5):
         out = (c_d * 3)()

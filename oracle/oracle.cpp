@@ -1681,21 +1681,39 @@ int orc_prepare(int64_t w, const double* o, const double* d, double* out) {
     out[29] = World::schlick(c);
     return 1;
 }
-// prepare_computations on a caller-supplied intersection list (hit_index into ts/objs), then one of
-// shade_hit / reflected_color / refracted_color / schlick (which: 0..3).
+// prepare_computations on a caller-supplied intersection list (hit_index into ts/objs, optional
+// uv pairs), then one of shade_hit (0) / reflected_color (1) / refracted_color (2) /
+// (schlick, n1, n2) (3) / the Computations themselves (4: same 30-double layout as orc_prepare).
+// World handle may be -1 for 3 and 4.
 int orc_comps_eval(int64_t w, const double* o, const double* d, const double* ts, const int64_t* objs,
-                   int n, int hit_index, int which, int remaining, double* out) {
+                   const double* uv, int n, int hit_index, int which, int remaining, double* out) {
     std::vector<Hit> xs;
-    for (int i = 0; i < n; ++i) xs.push_back({ts[i], g_reg.shapes.at(objs[i]).get(), 0, 0});
+    for (int i = 0; i < n; ++i)
+        xs.push_back({ts[i], g_reg.shapes.at(objs[i]).get(), uv ? uv[2 * i] : 0.0, uv ? uv[2 * i + 1] : 0.0});
     Ray r{t4(o), t4(d)};
     Comps c = World::prepare(hit_index, r, xs);
-    auto& world = g_reg.worlds.at(w);
     Color col{0, 0, 0};
     switch (which) {
-        case 0: col = world->shade_hit(c, remaining); break;
-        case 1: col = world->reflected_color(c, remaining); break;
-        case 2: col = world->refracted_color(c, remaining); break;
+        case 0: col = g_reg.worlds.at(w)->shade_hit(c, remaining); break;
+        case 1: col = g_reg.worlds.at(w)->reflected_color(c, remaining); break;
+        case 2: col = g_reg.worlds.at(w)->refracted_color(c, remaining); break;
         case 3: col = {World::schlick(c), c.n1, c.n2}; break;
+        case 4: {
+            out[0] = c.t;
+            put4(c.point, out + 1);
+            put4(c.over_point, out + 5);
+            put4(c.under_point, out + 9);
+            put4(c.eyev, out + 13);
+            put4(c.normalv, out + 17);
+            put4(c.reflectv, out + 21);
+            out[25] = c.n1;
+            out[26] = c.n2;
+            out[27] = c.inside ? 1.0 : 0.0;
+            auto it = g_reg.shape_ids.find(c.object);
+            out[28] = it == g_reg.shape_ids.end() ? -2.0 : (double)it->second;
+            out[29] = World::schlick(c);
+            return 0;
+        }
         default: return -1;
     }
     out[0] = col.r; out[1] = col.g; out[2] = col.b;

@@ -1,0 +1,136 @@
+"""The C ABI without a GPU: the library loads, exports every function include/rt_abi.h declares,
+its structs have the documented sizes, scene validation rejects malformed tables, and the row
+partition helpers are consistent."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(rt_[a-z_]+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    lib = abi.load()
+    names = declared_functions()
+    assert len(names) >= 11
+    for name in names:
+        assert hasattr(lib, name), name
+        assert name in abi.SYMBOLS, "abi.py does not bind " + name
+    assert sorted(abi.SYMBOLS) == names
+
+
+def test_struct_sizes():
+    assert C.sizeof(abi.rt_node) == 32
+    assert C.sizeof(abi.rt_xform) == 192
+    assert C.sizeof(abi.rt_aabb) == 48
+    assert C.sizeof(abi.rt_range) == 16
+    assert C.sizeof(abi.rt_tri) == 72 and C.sizeof(abi.rt_tri_normals) == 72
+    assert C.sizeof(abi.rt_material) == 64
+    assert C.sizeof(abi.rt_pattern) == 48
+    assert C.sizeof(abi.rt_light) == 48
+    assert C.sizeof(abi.rt_camera) == 128
+    assert C.sizeof(abi.rt_params) == 16
+    assert C.sizeof(abi.rt_stats) == 40
+
+
+def test_row_partition_helpers():
+    lib = abi.load()
+    for height in (1, 7, 8, 9, 90, 2160):
+        for ws in (1, 2, 3, 8):
+            seen = []
+            for rank in range(ws):
+                prm = abi.rt_params(5, rank, ws, 0)
+                n = lib.rt_local_rows(height, C.byref(prm))
+                rows = [lib.rt_global_row(i, C.byref(prm)) for i in range(n)]
+                assert all((r // 8) % ws == rank for r in rows)
+                assert rows == sorted(rows)
+                seen += rows
+            assert sorted(seen) == list(range(height))
+    bad = abi.rt_params(5, 2, 2, 0)
+    assert lib.rt_local_rows(10, C.byref(bad)) == -1
+
+
+def test_flatten_default_scene(host):
+    world = scenes.build_world(host)
+    counts = host.flatten(world)
+    assert counts == dict(nodes=30, xforms=19, aabbs=11, ranges=0, tris=0, materials=6, patterns=6,
+                          pattern_xforms=0, lights=2)
+    nodes = host.flat_nodes(world)
+    assert [n.type for n in nodes[:2]] == [2, 0]  # World objects: plane, then the group
+    for i, n in enumerate(nodes):
+        assert i < n.skip <= len(nodes) and n.parent < i and n.ctx == -1
+        if n.type != 0:
+            assert n.skip == i + 1 and n.material >= 0 and n.xform >= 0
+        else:
+            assert n.xform == -1  # every group here has the identity transform
+    assert nodes[1].skip == 30
+
+
+def test_flatten_transformed_group_sets_ctx(host):
+    M = host.Matrix
+    g = host.Group(M.scaling(2, 2, 2))
+    inner = host.Group()
+    s = host.Sphere(M.translation(5, 0, 0), host.Phong.default(), True)
+    inner.add_child(s)
+    g.add_child(inner)
+    world = host.World([g], [host.PointLight(host.point(0, 10, 0), host.Color.white())])
+    nodes = host.flat_nodes(world)
+    assert [n.ctx for n in nodes] == [-1, 0, 0]
+    assert [n.xform >= 0 for n in nodes] == [True, False, True]
+
+
+def test_scene_create_rejects_malformed_tables(host):
+    lib = host.abi
+    world = scenes.build_world(host)
+    desc = host.scene_desc(world)
+    handle = C.c_void_p()
+
+    def create(d):
+        return lib.rt_scene_create(C.byref(d), 0, C.byref(handle))
+
+    # a well-formed scene gets as far as looking for a device
+    assert create(desc) in (abi.RT_OK, abi.RT_ERR_NO_DEVICE)
+    if handle:
+        lib.rt_scene_destroy(handle)
+    nodes = (abi.rt_node * desc.n_nodes)(*[desc.nodes[i] for i in range(desc.n_nodes)])
+    broken = abi.rt_scene_desc.from_buffer_copy(desc)
+    broken.nodes = nodes
+    nodes[3].skip = 2
+    assert create(broken) == abi.RT_ERR_INVALID and b"skip" in lib.rt_last_error()
+    nodes[3].skip = 4
+    nodes[3].material = 99
+    assert create(broken) == abi.RT_ERR_INVALID and b"material" in lib.rt_last_error()
+    nodes[3].material = 1
+    nodes[5].ctx = 1
+    assert create(broken) == abi.RT_ERR_INVALID
+    nodes[5].ctx = -1
+    broken.n_lights = 5
+    assert create(broken) == abi.RT_ERR_LIMIT
+    assert lib.rt_scene_create(None, 0, C.byref(handle)) == abi.RT_ERR_INVALID
+
+
+def test_non_invertible_transform_is_an_error_not_a_crash(host):
+    M = host.Matrix
+    s = host.Sphere(M.scaling(0.01, 0.01, 0.01), host.Phong.default(), True)  # |det| < 1e-5: the reference panics
+    world = host.World([s], [])
+    with pytest.raises(abi.RtError):
+        host.flatten(world)
+
+
+def test_render_without_gpu_fails_loudly(host):
+    if host.abi.rt_device_count() > 0:
+        pytest.skip("a GPU is present")
+    world, cam = scenes.build_world(host), scenes.default_camera(host, 16, 16)
+    with pytest.raises(abi.RtError) as e:
+        host.render(world, cam)
+    assert e.value.code == abi.RT_ERR_NO_DEVICE
