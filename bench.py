@@ -100,10 +100,17 @@ def main():
         raise SystemExit("--gpus %d needs a torch.distributed launch with WORLD_SIZE=%d" % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
+    backend = os.environ.get("RT_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse N > 1 on one GPU
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()  # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world_size > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    stat_dev = dev if backend == "nccl" else torch.device("cpu")
 
     # N = 1: the single-GPU configuration (3840x2160); N > 1: the 8K frame split across ranks.
     W = args.width or (3840 if world_size == 1 else 7680)
@@ -149,7 +156,7 @@ def main():
     host.abi.rt_scene_ray_counts(scene, ctypes.byref(st))
     rays_local = st.total_rays()
 
-    t = torch.tensor([elapsed, kernel_ms, float(rays_local)], dtype=torch.float64, device=dev)
+    t = torch.tensor([elapsed, kernel_ms, float(rays_local)], dtype=torch.float64, device=stat_dev)
     if world_size > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

@@ -23,6 +23,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdint>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -84,6 +85,7 @@ struct DevJob {
     int rank, world_size, tiles_x, local_tile_rows;
     int max_depth;
     int xcd_remap;
+    int wide_stores;  // output base is 16-byte aligned and the width is even
     // ray-list mode (rt_color_at)
     long long n_rays;
     const double* ray_o;
@@ -984,7 +986,30 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
         }
     }
 
-    if (valid) {
+    // ---- write the tile ------------------------------------------------------------------------
+    // A tile row is 8 pixels = 192 contiguous bytes.  Lanes exchange their 24-byte pixels through
+    // LDS so that every lane stores 16-byte pieces and each store instruction covers whole rows
+    // (three 8-byte stores per lane with a 24-byte stride wrote every line three times).
+    __shared__ double tile_lds[4][64 * 3];
+    const bool whole_tile = J.wide_stores && __ballot(valid) == ~0ull;
+    if (whole_tile) {
+        double* t = tile_lds[wave];
+        t[lane * 3] = final_colour.x;
+        t[lane * 3 + 1] = final_colour.y;
+        t[lane * 3 + 2] = final_colour.z;
+        // rows of the tile are 8 pixels apart in the lane order, so the LDS image is already
+        // [row][192 bytes]; piece c (16 bytes) belongs to row c / 12, byte offset (c % 12) * 16
+        const long long row_stride = (long long)J.width * 3;                    // doubles
+        const long long base = (out_index - (lane & 7) - (long long)(lane >> 3) * J.width) * 3;  // tile origin
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int c = lane; c < 96; c += 64) {
+            const int row = c / 12, piece = c % 12;
+            double2 v = *reinterpret_cast<const double2*>(t + row * 24 + piece * 2);
+            *reinterpret_cast<double2*>(out + base + row * row_stride + piece * 2) = v;
+        }
+    } else if (valid) {
         out[out_index * 3] = final_colour.x;
         out[out_index * 3 + 1] = final_colour.y;
         out[out_index * 3 + 2] = final_colour.z;
@@ -1401,6 +1426,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, do
         job.xcd_remap = e ? atoi(e) : 0;
     }
     job.n_rays = 0;
+    job.wide_stores = ((reinterpret_cast<uintptr_t>(d_rgb) & 15) == 0 && (cam->width & 1) == 0) ? 1 : 0;
     long long tiles = (long long)job.tiles_x * job.local_tile_rows;
     if (tiles > 0 && !d_rgb) return fail(RT_ERR_INVALID, "null output buffer");
     long long blocks = (tiles + 3) / 4;

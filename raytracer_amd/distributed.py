@@ -30,6 +30,8 @@ class FrameGather:
     def __call__(self, local):
         """local: this rank's (rows, W, 3) float64 tensor.  Returns the full frame on rank dst."""
         assert tuple(local.shape) == (self.rows[self.rank], self.width, 3)
+        if self.world_size > 1 and local.is_cuda and dist.get_backend() == "gloo":
+            return self._staged(local)  # rehearsal only: gloo moves host memory
         if self.world_size > 1:
             if self.rank == self.dst:
                 ops = [dist.P2POp(dist.irecv, self.parts[r], r) for r in range(self.world_size)
@@ -39,6 +41,20 @@ class FrameGather:
             if ops:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
+        return self._place(local)
+
+    def _staged(self, local):
+        if self.rank == self.dst:
+            for r in range(self.world_size):
+                if r != self.dst and self.rows[r] > 0:
+                    tmp = torch.empty(self.parts[r].shape, dtype=torch.float64)
+                    dist.recv(tmp, r)
+                    self.parts[r].copy_(tmp)
+        elif self.rows[self.rank] > 0:
+            dist.send(local.cpu(), self.dst)
+        return self._place(local)
+
+    def _place(self, local):
         if self.rank != self.dst:
             return None
         for r in range(self.world_size):
