@@ -57,7 +57,26 @@ struct alignas(16) TRec {
 };
 static_assert(sizeof(TRec) == 128, "traversal record must be 128 bytes");
 
+// Shading record: everything the shading of a hit on one leaf needs, gathered so that a hit costs
+// one round of (per-lane) loads instead of a chain of dependent ones through the node, transform,
+// material and pattern tables.  Indexed by node.
+enum { S_HAS_XFORM = 1, S_CASTS_SHADOW = 2, S_SOLID = 4 };
+struct alignas(16) SRec {
+    int type, flags, pattern, n_levels;  // n_levels: the leaf plus all its ancestors
+    int anc_xf[4];                       // transforms of the transformed ancestors, nearest first, -1 padded
+    int anc_level[4];                    // how many levels above the leaf each of them is
+    int tri, pad0, pad1, pad2;           // triangle normals index
+    double inv[12];                      // the leaf's own inverse rows / transposed 3x3 (S_HAS_XFORM)
+    double inv_t[9];
+    double ka, kd, ks, shin, refl, transp, ri;  // Phong coefficients (phong.rs:10-19)
+    double colour[3];                    // S_SOLID: the pattern is one colour
+    double r0, r1;                       // cylinder / cone range
+    double pad3;
+};
+static_assert(sizeof(SRec) == 336, "shading record layout");
+
 struct DevScene {
+    const RT_CONST SRec* shade;
     const RT_CONST TRec* trav;
     int n_trav;
     const RT_CONST rt_node* nodes;
@@ -137,17 +156,11 @@ DI V3 xnormal(P t, V3 n) {
 // Applies, outermost first, the inverse transforms of the non-identity groups that enclose a node
 // whose `ctx` link is `ctx` (Shape::intersect applied level by level, src/geometry/shape.rs:23-29,
 // and Shape::world_to_object, shape.rs:65-79).  Identity levels are exact no-ops and are skipped.
-DI void chain_collect(const DevScene& S, int ctx, int c[RT_MAX_XFORM_NEST]) {
-    c[0] = ctx;
-#pragma unroll
-    for (int k = 1; k < RT_MAX_XFORM_NEST; ++k) c[k] = c[k - 1] >= 0 ? S.nodes[c[k - 1]].ctx : -1;
-}
-DI V3 chain_point(const DevScene& S, int ctx, V3 p) {
-    int c[RT_MAX_XFORM_NEST];
-    chain_collect(S, ctx, c);
+DI V3 to_object(const DevScene& S, const RT_CONST SRec* r, V3 p) {
 #pragma unroll
     for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
-        if (c[k] >= 0) p = xpoint(S.xforms[S.nodes[c[k]].xform].inv, p);
+        if (r->anc_xf[k] >= 0) p = xpoint(S.xforms[r->anc_xf[k]].inv, p);
+    if (r->flags & S_HAS_XFORM) p = xpoint(r->inv, p);
     return p;
 }
 // The same for a ray during traversal, on the traversal records (`ctx` is a record index there).
@@ -507,14 +520,26 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
 // the parent.  Identity levels skip the product but not the normalisation; once the magnitude is
 // exactly 1.0 further identity levels cannot change the vector, so the walk jumps to the next
 // enclosing non-identity group.
-DI V3 normal_to_world(const DevScene& S, int node, V3 n) {
-    int cur = node;
-    while (cur >= 0) {
-        int xf = S.nodes[cur].xform;
-        if (xf >= 0) n = xnormal(S.xforms[xf].inv_t, n);
-        double m = magnitude(n);
+DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
+    if (r->flags & S_HAS_XFORM) n = xnormal(r->inv_t, n);
+    double m = magnitude(n);
+    n = n / m;
+    const int n_levels = r->n_levels;
+    int level = 1;
+#pragma unroll
+    for (int k = 0; k <= RT_MAX_XFORM_NEST; ++k) {
+        const int xf = k < RT_MAX_XFORM_NEST ? r->anc_xf[k] : -1;
+        const int stop = xf >= 0 ? r->anc_level[k < RT_MAX_XFORM_NEST ? k : 0] : n_levels;
+        while (level < stop && m != 1.0) {  // identity ancestors: normalise only
+            m = magnitude(n);
+            n = n / m;
+            ++level;
+        }
+        if (xf < 0) break;
+        n = xnormal(S.xforms[xf].inv_t, n);
+        m = magnitude(n);
         n = n / m;
-        cur = (m == 1.0) ? S.nodes[cur].ctx : S.nodes[cur].parent;
+        level = stop + 1;
     }
     return n;
 }
@@ -757,24 +782,21 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
         double ka = 0.0, kd = 0.0, ks = 0.0, shin = 0.0, refl_c = 0.0, transp = 0.0;
         if (shade) {
             const int node = h.node;
-            const int type = S.nodes[node].type;
-            const int xf = S.nodes[node].xform;
-            const int data = S.nodes[node].data;
-            const int ctx = S.nodes[node].ctx;
-            const int mat = S.nodes[node].material;
+            const RT_CONST SRec* sr = S.shade + node;
+            const int type = sr->type;
+            const int sflags = sr->flags;
+            const int data = sr->tri;
             V3 point = ro + (rd * h.t);  // Ray::position (ray.rs:24-26)
             eyev = -rd;
             // Shape::normal_at (shape.rs:52-59)
-            V3 lp = chain_point(S, ctx, point);
-            if (xf >= 0) lp = xpoint(S.xforms[xf].inv, lp);
+            V3 lp = to_object(S, sr, point);
             V3 ln;
             switch (type) {
                 case RT_SPHERE:  // sphere.rs:109-111
                     ln = lp;
                     break;
                 case RT_PLANE:  // plane.rs:105-107: the plane's own inverse times (0, 1, 0)
-                    ln = xf >= 0 ? mk(S.xforms[xf].inv[1], S.xforms[xf].inv[5], S.xforms[xf].inv[9])
-                                 : mk(0.0, 1.0, 0.0);
+                    ln = (sflags & S_HAS_XFORM) ? mk(sr->inv[1], sr->inv[5], sr->inv[9]) : mk(0.0, 1.0, 0.0);
                     break;
                 case RT_CUBE: {  // cube.rs:129-142
                     double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
@@ -789,7 +811,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
                 }
                 case RT_CYLINDER:
                 case RT_CONE: {  // cylinder.rs:184-197, cone.rs:194-213
-                    double mn = S.ranges[data].minimum, mx = S.ranges[data].maximum;
+                    double mn = sr->r0, mx = sr->r1;
                     double dist = lp.x * lp.x + lp.z * lp.z;
                     if (dist < 1.0 && lp.y >= mx - RT_EPS) {
                         ln = mk(0.0, 1.0, 0.0);
@@ -814,7 +836,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
                     break;
                 }
             }
-            normalv = normal_to_world(S, node, ln);
+            normalv = normal_to_world(S, sr, ln);
             if (dot(normalv, eyev) < 0.0) normalv = -normalv;
             reflectv = reflect(rd, normalv);
             over = point + (normalv * RT_EPS);
@@ -822,30 +844,27 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
             if (TRACK) {
                 // Refractive indices of the last container before / after the hit (world.rs:103-132).
                 const int x_id = (h.a_id != node) ? h.a_id : h.b_id;  // latest container other than the hit leaf
-                const double ri_hit = S.mats[mat].refractive_index;
-                const double ri_x = x_id >= 0 ? S.mats[S.nodes[x_id].material].refractive_index : 1.0;
+                const double ri_hit = sr->ri;
+                const double ri_x = x_id >= 0 ? S.shade[x_id].ri : 1.0;
                 if (h.par) {  // the hit leaf is itself an open container: this is an exit
-                    n1 = S.mats[S.nodes[h.a_id].material].refractive_index;
+                    n1 = S.shade[h.a_id].ri;
                     n2 = ri_x;
                 } else {
                     n1 = ri_x;
                     n2 = ri_hit;
                 }
             }
-            ka = S.mats[mat].ambient;
-            kd = S.mats[mat].diffuse;
-            ks = S.mats[mat].specular;
-            shin = S.mats[mat].shininess;
-            refl_c = S.mats[mat].reflective;
-            transp = S.mats[mat].transparency;
+            ka = sr->ka;
+            kd = sr->kd;
+            ks = sr->ks;
+            shin = sr->shin;
+            refl_c = sr->refl;
+            transp = sr->transp;
             // Pattern::pattern_at_shape at over_point (phong.rs:68, pattern.rs:8-14)
-            const int pat = S.mats[mat].pattern;
-            if (S.pats[pat].type == RT_PAT_SOLID) {
-                colour = mk(S.pats[pat].color[0], S.pats[pat].color[1], S.pats[pat].color[2]);
+            if (sflags & S_SOLID) {
+                colour = mk(sr->colour[0], sr->colour[1], sr->colour[2]);
             } else {
-                V3 op = chain_point(S, ctx, over);
-                if (xf >= 0) op = xpoint(S.xforms[xf].inv, op);
-                colour = pattern_eval(S, pat, op);
+                colour = pattern_eval(S, sr->pattern, to_object(S, sr, over));
             }
         }
 
@@ -894,7 +913,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
             if (shade) {
                 ++n_shadow;
                 bool in_shadow = sh.found && sh.t < distance &&
-                                 (S.all_cast_shadow || (S.nodes[sh.node].flags & RT_NODE_CASTS_SHADOW));
+                                 (S.all_cast_shadow || (S.shade[sh.node].flags & S_CASTS_SHADOW));
                 V3 effective = colour * lint;
                 V3 ambient = effective * ka;
                 V3 surf = ambient;
@@ -1023,11 +1042,16 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
         atomicAdd(&counters[8], prof_traces);
         atomicAdd(&counters[9], prof_rounds);
         atomicAdd(&counters[10], 1ull);
+        atomicMax(&counters[11], __builtin_amdgcn_s_memtime() - prof_t0);
+        atomicMax(&counters[12], prof_rounds);
+        // histogram of wave durations in 2^k-cycle buckets is not kept; the maximum is what bounds the tail
     }
 #endif
     // Ray statistics: one atomic per wavefront and counter, spread over COUNTER_SHARDS copies so
     // that the 10^5 wavefronts of a frame do not serialise on four words.
+#ifndef RT_PROFILE
     counters += 16 * ((blockIdx.x * 4u + (unsigned)wave) % COUNTER_SHARDS);
+#endif
     unsigned c[4] = {n_primary, n_shadow, n_reflect, n_refract};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -1243,6 +1267,60 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
     return out;
 }
 
+// Gathers per-leaf shading data (see SRec).
+std::vector<SRec> build_shade_records(const rt_scene_desc* d) {
+    std::vector<SRec> out(d->n_nodes);
+    for (int i = 0; i < d->n_nodes; ++i) {
+        const rt_node& n = d->nodes[i];
+        SRec r{};
+        r.type = n.type;
+        r.flags = (n.flags & RT_NODE_CASTS_SHADOW) ? S_CASTS_SHADOW : 0;
+        r.pattern = -1;
+        r.tri = (n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE) ? n.data : -1;
+        for (int k = 0; k < 4; ++k) {
+            r.anc_xf[k] = -1;
+            r.anc_level[k] = 0;
+        }
+        int levels = 1, found = 0;
+        for (int p = n.parent; p >= 0; p = d->nodes[p].parent) {
+            if (d->nodes[p].xform >= 0 && found < 4) {
+                r.anc_xf[found] = d->nodes[p].xform;
+                r.anc_level[found] = levels;
+                ++found;
+            }
+            ++levels;
+        }
+        r.n_levels = levels;
+        if (n.xform >= 0) {
+            r.flags |= S_HAS_XFORM;
+            std::memcpy(r.inv, d->xforms[n.xform].inv, sizeof r.inv);
+            std::memcpy(r.inv_t, d->xforms[n.xform].inv_t, sizeof r.inv_t);
+        }
+        if (n.type != RT_GROUP) {
+            const rt_material& m = d->materials[n.material];
+            r.ka = m.ambient;
+            r.kd = m.diffuse;
+            r.ks = m.specular;
+            r.shin = m.shininess;
+            r.refl = m.reflective;
+            r.transp = m.transparency;
+            r.ri = m.refractive_index;
+            r.pattern = m.pattern;
+            const rt_pattern& p = d->patterns[m.pattern];
+            if (p.type == RT_PAT_SOLID) {
+                r.flags |= S_SOLID;
+                std::memcpy(r.colour, p.color, sizeof r.colour);
+            }
+        }
+        if (n.type == RT_CYLINDER || n.type == RT_CONE) {
+            r.r0 = d->ranges[n.data].minimum;
+            r.r1 = d->ranges[n.data].maximum;
+        }
+        out[i] = r;
+    }
+    return out;
+}
+
 int check_params(const rt_params* p) {
     if (!p) return fail(RT_ERR_INVALID, "null params");
     if (p->world_size < 1 || p->rank < 0 || p->rank >= p->world_size)
@@ -1293,8 +1371,8 @@ int fill_stats(rt_scene* s, rt_stats* st) {
 #ifdef RT_PROFILE
     {
         const unsigned long long* pc = c;
-        fprintf(stderr, "RT_PROFILE waves=%llu wave_cycles=%llu closest_cycles=%llu shadow_cycles=%llu visits=%llu traces=%llu rounds=%llu\n",
-                pc[10], pc[4], pc[5], pc[6], pc[7], pc[8], pc[9]);
+        fprintf(stderr, "RT_PROFILE waves=%llu wave_cycles=%llu closest_cycles=%llu shadow_cycles=%llu visits=%llu traces=%llu rounds=%llu max_wave_cycles=%llu max_rounds=%llu\n",
+                pc[10], pc[4], pc[5], pc[6], pc[7], pc[8], pc[9], pc[11], pc[12]);
     }
 #endif
     if (s->launches > 0) {
@@ -1335,6 +1413,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         rt_scene_destroy(s);
         return code;
     };
+    {
+        std::vector<SRec> srecs = build_shade_records(d);
+        if ((rc = upload(s, srecs.data(), srecs.size(), &s->dev.shade)) != RT_OK) return cleanup(rc);
+    }
     {
         std::vector<TRec> recs = build_records(d);
         if ((rc = upload(s, recs.data(), recs.size(), &s->dev.trav)) != RT_OK) return cleanup(rc);
