@@ -222,7 +222,21 @@ DI void slabs_fast(V3 o, V3 d, V3 y, double x0, double y0, double z0, double x1,
     tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
 }
 DI bool all_axes_finite(V3 d) { return fabs(d.x) >= RT_EPS && fabs(d.y) >= RT_EPS && fabs(d.z) >= RT_EPS; }
-DI V3 reciprocal(V3 d) { return mk(1.0 / d.x, 1.0 / d.y, 1.0 / d.z); }
+// Correctly rounded 1/d for normal-range d (the callers only use it where |d| >= RT_EPS and d is a
+// ray direction component): hardware estimate, two Newton steps, then the residual correction
+// that makes the result the IEEE quotient 1.0 / d.  This is the compiler's own f64 division
+// expansion without the operand scaling and special-case fix-up that only matter near the ends
+// of the exponent range (rt_selftest_division compares it with 1.0 / d on the device).
+DI double rcp_exact(double d) {
+    double y = __builtin_amdgcn_rcp(d);
+    double e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-d, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    double r = __builtin_fma(-d, y, 1.0);
+    return __builtin_fma(r, y, y);
+}
+DI V3 reciprocal(V3 d) { return mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z)); }
 
 // Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
 // for the n1/n2 bookkeeping, the parity and the latest of the leaf's non-positive times.
@@ -703,8 +717,12 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
 #ifndef RT_MIN_WAVES
 #define RT_MIN_WAVES 1
 #endif
+#ifndef RT_BLOCK_WAVES
+#define RT_BLOCK_WAVES 1  // wavefronts (8x8 tiles) per workgroup; one gives the dispatcher the finest grain
+#endif
+#define RT_BLOCK (RT_BLOCK_WAVES * 64)
 template <bool TRACK>
-__global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
+__global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -729,7 +747,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
             unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
             b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
         }
-        const long long tile = (long long)b * 4 + wave;
+        const long long tile = (long long)b * RT_BLOCK_WAVES + wave;
         const int tx = (int)(tile % J.tiles_x);
         const int lty = (int)(tile / J.tiles_x);
         const int px = tx * RT_TILE + (lane & 7);
@@ -1009,7 +1027,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
     // A tile row is 8 pixels = 192 contiguous bytes.  Lanes exchange their 24-byte pixels through
     // LDS so that every lane stores 16-byte pieces and each store instruction covers whole rows
     // (three 8-byte stores per lane with a 24-byte stride wrote every line three times).
-    __shared__ double tile_lds[4][64 * 3];
+    __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
     const bool whole_tile = J.wide_stores && __ballot(valid) == ~0ull;
     if (whole_tile) {
         double* t = tile_lds[wave];
@@ -1050,7 +1068,7 @@ __global__ void __launch_bounds__(256, RT_MIN_WAVES) rt_kernel(DevScene S, DevJo
     // Ray statistics: one atomic per wavefront and counter, spread over COUNTER_SHARDS copies so
     // that the 10^5 wavefronts of a frame do not serialise on four words.
 #ifndef RT_PROFILE
-    counters += 16 * ((blockIdx.x * 4u + (unsigned)wave) % COUNTER_SHARDS);
+    counters += 16 * ((blockIdx.x * (unsigned)RT_BLOCK_WAVES + (unsigned)wave) % COUNTER_SHARDS);
 #endif
     unsigned c[4] = {n_primary, n_shadow, n_reflect, n_refract};
 #pragma unroll
@@ -1067,8 +1085,8 @@ __global__ void division_selftest_kernel(long long n, const double* a, const dou
                                          double* out_ieee) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) {
-        double y = 1.0 / d[i];
-        out_fast[i] = div_by(a[i], d[i], y);
+        double y = rcp_exact(d[i]);
+        out_fast[i] = (y == 1.0 / d[i]) ? div_by(a[i], d[i], y) : __builtin_nan("");
         out_ieee[i] = a[i] / d[i];
     }
 }
@@ -1342,10 +1360,10 @@ int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipSt
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (blocks > 0) {
         if (s->any_transparent)
-            hipLaunchKernelGGL(rt_kernel<true>, dim3(blocks), dim3(256), 0, stream, s->dev, job, d_out,
+            hipLaunchKernelGGL(rt_kernel<true>, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out,
                                s->d_counters);
         else
-            hipLaunchKernelGGL(rt_kernel<false>, dim3(blocks), dim3(256), 0, stream, s->dev, job, d_out,
+            hipLaunchKernelGGL(rt_kernel<false>, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out,
                                s->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -1511,7 +1529,7 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, do
     job.wide_stores = ((reinterpret_cast<uintptr_t>(d_rgb) & 15) == 0 && (cam->width & 1) == 0) ? 1 : 0;
     long long tiles = (long long)job.tiles_x * job.local_tile_rows;
     if (tiles > 0 && !d_rgb) return fail(RT_ERR_INVALID, "null output buffer");
-    long long blocks = (tiles + 3) / 4;
+    long long blocks = (tiles + RT_BLOCK_WAVES - 1) / RT_BLOCK_WAVES;
     if (blocks > 0x7fffffffLL) return fail(RT_ERR_LIMIT, "frame too large for one launch");
     return launch(s, job, (unsigned)blocks, d_rgb, (hipStream_t)hip_stream);
 }
@@ -1569,7 +1587,7 @@ int rt_color_at(rt_scene* s, int64_t n, const double* origins, const double* dir
     job.ray_o = d_o;
     job.ray_d = d_d;
     job.world_size = 1;
-    long long blocks = (n + 255) / 256;
+    long long blocks = (n + RT_BLOCK - 1) / RT_BLOCK;
     if (blocks > 0x7fffffffLL) return fail(RT_ERR_LIMIT, "too many rays for one launch");
     int rc = launch(s, job, (unsigned)blocks, d_c, nullptr);
     if (rc != RT_OK) return rc;
