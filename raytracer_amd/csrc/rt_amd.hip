@@ -291,7 +291,9 @@ enum { MODE_CLOSEST = 0, MODE_CLOSEST_TRACK = 1, MODE_SHADOW = 2 };
 // wave-uniform control flow; lanes without a ray pass active = false.
 // MODE_SHADOW: `limit` is the distance to the light; when every leaf casts a shadow a lane stops
 // at its first intersection in (0, limit) (any such intersection implies the nearest one is too).
-template <int MODE>
+// XF: the scene has transformed groups or triangles (T_XFORM records); without them the ray never
+// changes space between records and the world-space copy is not kept.
+template <int MODE, bool XF>
 DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
     constexpr bool TRACK = MODE == MODE_CLOSEST_TRACK;
     h.found = false;
@@ -342,7 +344,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         asm volatile("" ::"s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]),
                      "s"(q[8]), "s"(q[9]), "s"(q[10]), "s"(q[11]));
         const int type = kind & 0xff;
-        if (ctx != cur_ctx) {
+        if (XF && ctx != cur_ctx) {
             co = wo;
             cd = wd;
             chain_ray(S, ctx, co, cd);
@@ -351,7 +353,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             cur_ctx = ctx;
         }
         const bool act = i >= skip_until;
-        if (type == T_XFORM) {
+        if (XF && type == T_XFORM) {
             // The inverse of a transformed group (or triangle): the records after it, up to the
             // end of the node's subtree, see the ray in that node's space.
             V3 to = xpoint(q, co), td = xvec(q, cd);
@@ -695,6 +697,7 @@ struct Frame {
     double surf[RT_MAX_LIGHTS][3];  // surface colour per light, in light order
     double refl[3];                 // reflected colour * reflective
     double rray[6];                 // pending refraction ray (under_point, direction)
+    double first[3];                // direction of the reflection ray (origin: over_point)
     double k;                       // Schlick reflectance
     double transparency;
     double reflective;
@@ -721,14 +724,37 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
 #define RT_BLOCK_WAVES 1  // wavefronts (8x8 tiles) per workgroup; one gives the dispatcher the finest grain
 #endif
 #define RT_BLOCK (RT_BLOCK_WAVES * 64)
-template <bool TRACK>
+// Pixel of this lane: column, row within this rank's compact buffer, and local tile row.
+// Workgroups are dealt round-robin to the 8 XCDs; the optional remap gives each XCD a contiguous
+// band of tiles.  Cheap enough to evaluate twice instead of holding the result in registers.
+DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, int& lty) {
+    const unsigned nwg = gridDim.x;
+    unsigned b = blockIdx.x;
+    if (J.xcd_remap) {
+        unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
+        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const long long tile = (long long)b * RT_BLOCK_WAVES + wave;
+    const int tx = (int)(tile % J.tiles_x);
+    lty = (int)(tile / J.tiles_x);
+    px = tx * RT_TILE + (lane & 7);
+    local_y = lty * RT_TILE + (lane >> 3);
+}
+
+template <bool TRACK, bool XF>
 __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    // A lane parks its finished pixel in LDS instead of carrying it through the rest of the
+    // wavefront's rounds; the tile is written from there at the end.
+    __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
+    double* const my_pixel = tile_lds[wave] + lane * 3;
+    my_pixel[0] = 0.0;
+    my_pixel[1] = 0.0;
+    my_pixel[2] = 0.0;
 
     bool pending;
-    long long out_index;
     V3 ro, rd;
     if (J.n_rays > 0) {
         // World::color_at for caller-supplied rays.
@@ -737,24 +763,11 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
         long long rr = pending ? r : 0;
         ro = mk(J.ray_o[rr * 3], J.ray_o[rr * 3 + 1], J.ray_o[rr * 3 + 2]);
         rd = mk(J.ray_d[rr * 3], J.ray_d[rr * 3 + 1], J.ray_d[rr * 3 + 2]);
-        out_index = rr;
     } else {
-        // Workgroups are dealt round-robin to the 8 XCDs; remap so that each XCD renders a
-        // contiguous band of tiles and its L2 sees a spatially coherent part of the scene.
-        const unsigned nwg = gridDim.x;
-        unsigned b = blockIdx.x;
-        if (J.xcd_remap) {
-            unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
-            b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        }
-        const long long tile = (long long)b * RT_BLOCK_WAVES + wave;
-        const int tx = (int)(tile % J.tiles_x);
-        const int lty = (int)(tile / J.tiles_x);
-        const int px = tx * RT_TILE + (lane & 7);
-        const int local_y = lty * RT_TILE + (lane >> 3);
+        int px, local_y, lty;
+        lane_pixel(J, wave, lane, px, local_y, lty);
         const int py = (lty * J.world_size + J.rank) * RT_TILE + (lane >> 3);
         pending = lty < J.local_tile_rows && px < J.width && py < J.height;
-        out_index = (long long)local_y * J.width + px;
         // Camera::ray_for_pixel (camera.rs:47-66)
         double x_offset = ((double)px + 0.5) * J.pixel_size;
         double y_offset = ((double)py + 0.5) * J.pixel_size;
@@ -772,7 +785,6 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
     unsigned n_primary = pending ? 1u : 0u, n_shadow = 0u, n_reflect = 0u, n_refract = 0u;
     Frame frames[RT_MAX_FRAMES];
     int sp = 0;  // suspended calls; the ray being traced has remaining = max_depth - sp
-    V3 final_colour = mk(0.0, 0.0, 0.0);
     const int L = S.n_lights;
 
 #ifdef RT_PROFILE
@@ -784,7 +796,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
 #ifdef RT_PROFILE
         unsigned long long pt = __builtin_amdgcn_s_memtime();
 #endif
-        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST>(S, pending, ro, rd, 0.0, h);
+        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST, XF>(S, pending, ro, rd, 0.0, h);
 #ifdef RT_PROFILE
         prof_closest += __builtin_amdgcn_s_memtime() - pt;
         prof_visits += h.visits;
@@ -792,20 +804,20 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
         prof_rounds += 1;
 #endif
         const bool shade = pending && h.found;
+        const int node = shade ? h.node : 0;
+        const RT_CONST SRec* sr = S.shade + node;
 
         // ---- World::prepare_computations (world.rs:70-147) --------------------------------
-        V3 over = mk(0.0, 0.0, 0.0), under = over, eyev = over, normalv = over, reflectv = over;
-        V3 colour = over;
-        double n1 = 1.0, n2 = 1.0;
-        double ka = 0.0, kd = 0.0, ks = 0.0, shin = 0.0, refl_c = 0.0, transp = 0.0;
+        // Only what the light loop needs stays in registers: over_point, normalv and the
+        // pattern colour.  Everything about the secondary rays goes into the lane's frame now.
+        V3 over = mk(0.0, 0.0, 0.0), normalv = over, colour = over;
+        bool want_refl = false, want_refr = false;
         if (shade) {
-            const int node = h.node;
-            const RT_CONST SRec* sr = S.shade + node;
             const int type = sr->type;
             const int sflags = sr->flags;
             const int data = sr->tri;
             V3 point = ro + (rd * h.t);  // Ray::position (ray.rs:24-26)
-            eyev = -rd;
+            V3 eyev = -rd;
             // Shape::normal_at (shape.rs:52-59)
             V3 lp = to_object(S, sr, point);
             V3 ln;
@@ -856,47 +868,30 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
             }
             normalv = normal_to_world(S, sr, ln);
             if (dot(normalv, eyev) < 0.0) normalv = -normalv;
-            reflectv = reflect(rd, normalv);
             over = point + (normalv * RT_EPS);
-            under = point - (normalv * RT_EPS);
+
+            // ---- which secondary rays this hit needs (world.rs:214-275) ----------------------
+            const int remaining = J.max_depth - sp;
+            const double refl_c = sr->refl, transp = sr->transp;
+            want_refl = remaining > 0 && !(fabs(refl_c - 0.0) < RT_EPS);
+            V3 refr_dir = mk(0.0, 0.0, 0.0);
+            double kk = 0.0;
+            bool use_k = false;
             if (TRACK) {
                 // Refractive indices of the last container before / after the hit (world.rs:103-132).
+                double n1, n2;
                 const int x_id = (h.a_id != node) ? h.a_id : h.b_id;  // latest container other than the hit leaf
-                const double ri_hit = sr->ri;
                 const double ri_x = x_id >= 0 ? S.shade[x_id].ri : 1.0;
                 if (h.par) {  // the hit leaf is itself an open container: this is an exit
                     n1 = S.shade[h.a_id].ri;
                     n2 = ri_x;
                 } else {
                     n1 = ri_x;
-                    n2 = ri_hit;
+                    n2 = sr->ri;
                 }
-            }
-            ka = sr->ka;
-            kd = sr->kd;
-            ks = sr->ks;
-            shin = sr->shin;
-            refl_c = sr->refl;
-            transp = sr->transp;
-            // Pattern::pattern_at_shape at over_point (phong.rs:68, pattern.rs:8-14)
-            if (sflags & S_SOLID) {
-                colour = mk(sr->colour[0], sr->colour[1], sr->colour[2]);
-            } else {
-                colour = pattern_eval(S, sr->pattern, to_object(S, sr, over));
-            }
-        }
-
-        // ---- which secondary rays this hit needs (world.rs:214-275) --------------------------
-        const int remaining = J.max_depth - sp;
-        bool want_refl = false, want_refr = false, use_k = false;
-        V3 refr_dir = mk(0.0, 0.0, 0.0);
-        double kk = 0.0;
-        if (shade) {
-            want_refl = remaining > 0 && !(fabs(refl_c - 0.0) < RT_EPS);
-            if (TRACK) {
+                const double cos_i = dot(eyev, normalv);
                 if (remaining > 0 && !(fabs(transp - 0.0) < RT_EPS)) {
                     double n_ratio = n1 / n2;
-                    double cos_i = dot(eyev, normalv);
                     double sin2_t = (n_ratio * n_ratio) * (1.0 - (cos_i * cos_i));
                     if (!(sin2_t > 1.0)) {
                         double cos_t = sqrt(1.0 - sin2_t);
@@ -904,8 +899,35 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
                         want_refr = true;
                     }
                 }
-                use_k = refl_c > 0.0 && transp > 0.0;
-                if (use_k && (want_refl || want_refr)) kk = schlick(dot(eyev, normalv), n1, n2);
+                use_k = refl_c > 0.0 && transp > 0.0;  // world.rs:185
+                if (use_k && (want_refl || want_refr)) kk = schlick(cos_i, n1, n2);
+            }
+            if (want_refl || want_refr) {
+                Frame& f = frames[sp];
+                V3 under = point - (normalv * RT_EPS);
+                V3 reflectv = reflect(rd, normalv);
+                f.k = kk;
+                f.reflective = refl_c;
+                f.transparency = transp;
+                f.first[0] = reflectv.x;
+                f.first[1] = reflectv.y;
+                f.first[2] = reflectv.z;
+                f.rray[0] = under.x;
+                f.rray[1] = under.y;
+                f.rray[2] = under.z;
+                f.rray[3] = refr_dir.x;
+                f.rray[4] = refr_dir.y;
+                f.rray[5] = refr_dir.z;
+                f.refl[0] = 0.0;
+                f.refl[1] = 0.0;
+                f.refl[2] = 0.0;
+                f.state = want_refl ? ((want_refr ? 2 : 0) | (use_k ? 4 : 0)) : (1 | (use_k ? 4 : 0));
+            }
+            // Pattern::pattern_at_shape at over_point (phong.rs:68, pattern.rs:8-14)
+            if (sflags & S_SOLID) {
+                colour = mk(sr->colour[0], sr->colour[1], sr->colour[2]);
+            } else {
+                colour = pattern_eval(S, sr->pattern, to_object(S, sr, over));
             }
         }
         const bool has_children = want_refl || want_refr;
@@ -914,7 +936,6 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
         V3 acc = mk(0.0, 0.0, 0.0);
         for (int l = 0; l < L; ++l) {
             V3 lpos = mk(S.lights[l].position[0], S.lights[l].position[1], S.lights[l].position[2]);
-            V3 lint = mk(S.lights[l].intensity[0], S.lights[l].intensity[1], S.lights[l].intensity[2]);
             V3 lv = lpos - over;
             double distance = magnitude(lv);
             V3 lightv = lv / distance;
@@ -922,7 +943,7 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
 #ifdef RT_PROFILE
             unsigned long long ps = __builtin_amdgcn_s_memtime();
 #endif
-            trace<MODE_SHADOW>(S, shade, over, lightv, distance, sh);
+            trace<MODE_SHADOW, XF>(S, shade, over, lightv, distance, sh);
 #ifdef RT_PROFILE
             prof_shadow += __builtin_amdgcn_s_memtime() - ps;
             prof_visits += sh.visits;
@@ -932,19 +953,21 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
                 ++n_shadow;
                 bool in_shadow = sh.found && sh.t < distance &&
                                  (S.all_cast_shadow || (S.shade[sh.node].flags & S_CASTS_SHADOW));
+                V3 lint = mk(S.lights[l].intensity[0], S.lights[l].intensity[1], S.lights[l].intensity[2]);
                 V3 effective = colour * lint;
-                V3 ambient = effective * ka;
+                V3 ambient = effective * sr->ka;
                 V3 surf = ambient;
                 if (!in_shadow) {
                     V3 diffuse = mk(0.0, 0.0, 0.0), specular = diffuse;
                     double ldn = dot(lightv, normalv);
                     if (!(ldn < 0.0)) {
-                        diffuse = effective * kd * ldn;
+                        diffuse = effective * sr->kd * ldn;
                         V3 rv = reflect(-lightv, normalv);
-                        double rde = dot(rv, eyev);
+                        double rde = dot(rv, -rd);
                         if (!(rde <= 0.0)) {
                             // a zero specular coefficient makes the term an exact zero; skip pow
-                            double factor = (ks == 0.0) ? 1.0 : pow(rde, shin);
+                            const double ks = sr->ks;
+                            double factor = (ks == 0.0) ? 1.0 : pow(rde, sr->shin);
                             specular = lint * ks * factor;
                         }
                     }
@@ -964,29 +987,15 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
         if (pending) {
             V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
             bool returning = true;
-            if (shade && has_children) {
-                Frame& f = frames[sp];
-                f.k = kk;
-                f.reflective = refl_c;
-                f.transparency = transp;
-                f.rray[0] = under.x;
-                f.rray[1] = under.y;
-                f.rray[2] = under.z;
-                f.rray[3] = refr_dir.x;
-                f.rray[4] = refr_dir.y;
-                f.rray[5] = refr_dir.z;
+            if (has_children) {
+                const Frame& f = frames[sp];
                 if (want_refl) {
-                    f.state = (want_refr ? 2 : 0) | (use_k ? 4 : 0);
                     ro = over;
-                    rd = reflectv;
+                    rd = mk(f.first[0], f.first[1], f.first[2]);
                     ++n_reflect;
                 } else {
-                    f.refl[0] = 0.0;
-                    f.refl[1] = 0.0;
-                    f.refl[2] = 0.0;
-                    f.state = 1 | (use_k ? 4 : 0);
-                    ro = under;
-                    rd = refr_dir;
+                    ro = mk(f.rray[0], f.rray[1], f.rray[2]);
+                    rd = mk(f.rray[3], f.rray[4], f.rray[5]);
                     ++n_refract;
                 }
                 ++sp;
@@ -994,7 +1003,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
             }
             while (returning) {
                 if (sp == 0) {
-                    final_colour = value;
+                    my_pixel[0] = value.x;
+                    my_pixel[1] = value.y;
+                    my_pixel[2] = value.z;
                     pending = false;
                     break;
                 }
@@ -1024,22 +1035,26 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
     }
 
     // ---- write the tile ------------------------------------------------------------------------
-    // A tile row is 8 pixels = 192 contiguous bytes.  Lanes exchange their 24-byte pixels through
-    // LDS so that every lane stores 16-byte pieces and each store instruction covers whole rows
-    // (three 8-byte stores per lane with a 24-byte stride wrote every line three times).
-    __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
+    // A tile row is 8 pixels = 192 contiguous bytes.  The pixels sit in LDS in lane order, so every
+    // lane stores 16-byte pieces and each store instruction covers whole rows (three 8-byte
+    // stores per lane with a 24-byte stride would write every line three times).
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
+    __builtin_amdgcn_wave_barrier();
+    long long out_index;
+    if (J.n_rays > 0) {
+        out_index = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    } else {
+        int px, local_y, lty;
+        lane_pixel(J, wave, lane, px, local_y, lty);
+        out_index = (long long)local_y * J.width + px;
+    }
     const bool whole_tile = J.wide_stores && __ballot(valid) == ~0ull;
     if (whole_tile) {
-        double* t = tile_lds[wave];
-        t[lane * 3] = final_colour.x;
-        t[lane * 3 + 1] = final_colour.y;
-        t[lane * 3 + 2] = final_colour.z;
+        const double* t = tile_lds[wave];
         // rows of the tile are 8 pixels apart in the lane order, so the LDS image is already
         // [row][192 bytes]; piece c (16 bytes) belongs to row c / 12, byte offset (c % 12) * 16
         const long long row_stride = (long long)J.width * 3;                    // doubles
         const long long base = (out_index - (lane & 7) - (long long)(lane >> 3) * J.width) * 3;  // tile origin
-        __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
-        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int c = lane; c < 96; c += 64) {
             const int row = c / 12, piece = c % 12;
@@ -1047,9 +1062,9 @@ __global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, 
             *reinterpret_cast<double2*>(out + base + row * row_stride + piece * 2) = v;
         }
     } else if (valid) {
-        out[out_index * 3] = final_colour.x;
-        out[out_index * 3 + 1] = final_colour.y;
-        out[out_index * 3 + 2] = final_colour.z;
+        out[out_index * 3] = my_pixel[0];
+        out[out_index * 3 + 1] = my_pixel[1];
+        out[out_index * 3 + 2] = my_pixel[2];
     }
 #ifdef RT_PROFILE
     if (lane == 0) {
@@ -1115,6 +1130,7 @@ struct rt_scene {
     int device = 0;
     DevScene dev{};
     bool any_transparent = false;
+    bool any_xform = false;  // the traversal records include T_XFORM entries
     std::vector<void*> allocations;
     unsigned long long* d_counters = nullptr;
     double* d_frame = nullptr;  // staging for the synchronous entry points
@@ -1359,12 +1375,9 @@ int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipSt
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, COUNTER_SHARDS * 16 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (blocks > 0) {
-        if (s->any_transparent)
-            hipLaunchKernelGGL(rt_kernel<true>, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out,
-                               s->d_counters);
-        else
-            hipLaunchKernelGGL(rt_kernel<false>, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out,
-                               s->d_counters);
+        auto kernel = s->any_transparent ? (s->any_xform ? rt_kernel<true, true> : rt_kernel<true, false>)
+                                         : (s->any_xform ? rt_kernel<false, true> : rt_kernel<false, false>);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, s->d_counters);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(s->ev_stop[slot], stream));
@@ -1439,6 +1452,8 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         std::vector<TRec> recs = build_records(d);
         if ((rc = upload(s, recs.data(), recs.size(), &s->dev.trav)) != RT_OK) return cleanup(rc);
         s->dev.n_trav = (int)recs.size();
+        for (const TRec& r : recs)
+            if ((r.kind & 0xff) == T_XFORM) s->any_xform = true;
     }
     if ((rc = upload(s, d->nodes, d->n_nodes, &s->dev.nodes)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms)) != RT_OK) return cleanup(rc);
