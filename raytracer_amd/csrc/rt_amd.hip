@@ -45,7 +45,10 @@ namespace {
 // step costs a single scalar-load round trip.  Records follow the pre-order of the node table; a
 // node whose transform is not the identity AND which carries its own payload (a transformed group
 // or triangle) is preceded by an extra T_XFORM record that holds its inverse.
-enum { T_XFORM = 8, T_HAS_INV = 0x100, T_CLOSED = 0x200, T_OWN_XFORM = 0x400 };
+// A finite sphere, cube or cylinder leaf is preceded by a T_CULL record: a padded box
+// around the leaf in the space its ray arrives in.  Lanes whose ray cannot reach the box skip
+// the leaf; this never changes a result, it only avoids arithmetic whose outcome is "no hit".
+enum { T_XFORM = 8, T_CULL = 9, T_HAS_INV = 0x100, T_CLOSED = 0x200, T_OWN_XFORM = 0x400 };
 struct alignas(16) TRec {
     int kind;    // low byte: RT_* type or T_XFORM; T_HAS_INV: p holds rows 0..2 of the inverse; T_CLOSED;
                  // T_OWN_XFORM: the record before this one is this node's T_XFORM record
@@ -236,7 +239,11 @@ DI double rcp_exact(double d) {
     double r = __builtin_fma(-d, y, 1.0);
     return __builtin_fma(r, y, y);
 }
-DI V3 reciprocal(V3 d) { return mk(rcp_exact(d.x), rcp_exact(d.y), rcp_exact(d.z)); }
+// Components the reference treats as parallel to a slab (|d| < RT_EPS, bounding_box.rs:107-113)
+// get NaN: the fast slab test is only used when no lane has one, and the cull test then leaves
+// that axis unconstrained.
+DI double reciprocal1(double d) { return fabs(d) >= RT_EPS ? rcp_exact(d) : __builtin_nan(""); }
+DI V3 reciprocal(V3 d) { return mk(reciprocal1(d.x), reciprocal1(d.y), reciprocal1(d.z)); }
 
 // Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
 // for the n1/n2 bookkeeping, the parity and the latest of the leaf's non-positive times.
@@ -317,6 +324,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     int cur_ctx = -1;
     V3 co = wo, cd = wd;  // the ray in the space of the transformed group `cur_ctx`
     V3 cy = reciprocal(cd);  // exact reciprocals of cd, used by the fast slab test
+    double coo = dot(co, co);  // scales the padding of T_CULL boxes
     bool cfin = all_axes_finite(cd);
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
 
@@ -349,6 +357,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             cd = wd;
             chain_ray(S, ctx, co, cd);
             cy = reciprocal(cd);
+            coo = dot(co, co);
             cfin = all_axes_finite(cd);
             cur_ctx = ctx;
         }
@@ -360,9 +369,31 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             co = to;
             cd = td;
             cy = reciprocal(cd);
+            coo = dot(co, co);
             cfin = all_axes_finite(cd);
             cur_ctx = i;
             i = i + 1;
+            continue;
+        }
+        if (type == T_CULL) {
+            // Box p[0..5] grown by r0 + r1 * |origin|^2: r0 covers the rounding of this test, the
+            // second term the rounding of the leaf's own quadratic for far-away origins (its
+            // discriminant loses about eps * |origin|^2, which can turn a near miss into a hit).
+            // NaN times (zero direction components) leave their axis unconstrained.
+            const double pad = __builtin_fma(r1, coo, r0);
+            const V3 om = mk(co.x + pad, co.y + pad, co.z + pad), op = mk(co.x - pad, co.y - pad, co.z - pad);
+            double ax = (q[0] - om.x) * cy.x, bx = (q[3] - op.x) * cy.x;
+            double ay = (q[1] - om.y) * cy.y, by = (q[4] - op.y) * cy.y;
+            double az = (q[2] - om.z) * cy.z, bz = (q[5] - op.z) * cy.z;
+            double tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+            double tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+            bool keep = !(tmin > tmax);
+            if (!TRACK) keep = keep && !(tmax < 0.0);                     // only positive times count
+            if (MODE == MODE_SHADOW) keep = keep && !(tmin > limit);     // beyond the light
+            keep = keep && !(h.found && tmin > h.t);                     // behind the nearest hit so far
+            keep = keep && act;
+            if (act && !keep) skip_until = skip;
+            i = (__ballot(keep) == 0ull) ? skip : i + 1;
             continue;
         }
         if (type == RT_GROUP) {
@@ -717,8 +748,13 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
     return acc;
 }
 
+// Wavefronts per SIMD the register allocation aims for: scenes with transformed groups carry a
+// second copy of the ray and get one fewer.
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 1
+#define RT_MIN_WAVES 5
+#endif
+#ifndef RT_MIN_WAVES_XF
+#define RT_MIN_WAVES_XF 4
 #endif
 #ifndef RT_BLOCK_WAVES
 #define RT_BLOCK_WAVES 1  // wavefronts (8x8 tiles) per workgroup; one gives the dispatcher the finest grain
@@ -742,7 +778,7 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, i
 }
 
 template <bool TRACK, bool XF>
-__global__ void __launch_bounds__(RT_BLOCK, RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
+__global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1251,6 +1287,83 @@ int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
     return RT_OK;
 }
 
+// Forward matrix (rows 0..2) of an affine map given rows 0..2 of its inverse.  Only used for
+// conservative boxes, so ordinary rounding is fine.
+bool affine_forward(const double inv[12], double fwd[12]) {
+    const double a = inv[0], b = inv[1], c = inv[2], e = inv[4], f = inv[5], g = inv[6], i = inv[8], j = inv[9],
+                 k = inv[10];
+    const double det = a * (f * k - g * j) - b * (e * k - g * i) + c * (e * j - f * i);
+    if (!(std::fabs(det) > 0.0) || !std::isfinite(det)) return false;
+    const double r = 1.0 / det;
+    fwd[0] = (f * k - g * j) * r;
+    fwd[1] = (c * j - b * k) * r;
+    fwd[2] = (b * g - c * f) * r;
+    fwd[4] = (g * i - e * k) * r;
+    fwd[5] = (a * k - c * i) * r;
+    fwd[6] = (c * e - a * g) * r;
+    fwd[8] = (e * j - f * i) * r;
+    fwd[9] = (b * i - a * j) * r;
+    fwd[10] = (a * f - b * e) * r;
+    for (int row = 0; row < 3; ++row)
+        fwd[row * 4 + 3] = -(fwd[row * 4] * inv[3] + fwd[row * 4 + 1] * inv[7] + fwd[row * 4 + 2] * inv[11]);
+    for (int n = 0; n < 12; ++n)
+        if (!std::isfinite(fwd[n])) return false;
+    return true;
+}
+
+// The T_CULL record of a finite sphere, cube or cylinder leaf, or false when the leaf is unbounded
+// (open-ended cylinders) or its transform is too degenerate to bound.
+bool cull_record(const rt_scene_desc* d, const rt_node& n, TRec& out) {
+    // Cones are left out: for a ray parallel to one half of the cone the reference reports the
+    // single wall intersection without the minimum < y < maximum check (cone.rs:119-127), so a
+    // truncated cone can be hit outside any box around it.
+    static const bool disabled = getenv("RT_NO_CULL") && atoi(getenv("RT_NO_CULL")) != 0;
+    if (disabled) return false;
+    double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};
+    if (n.type == RT_CYLINDER) {
+        const double mn = d->ranges[n.data].minimum, mx = d->ranges[n.data].maximum;
+        if (!std::isfinite(mn) || !std::isfinite(mx)) return false;
+        lo[1] = std::fmin(mn, mx);
+        hi[1] = std::fmax(mn, mx);
+    } else if (n.type != RT_SPHERE && n.type != RT_CUBE) {
+        return false;
+    }
+    double fwd[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    if (n.xform >= 0 && !affine_forward(d->xforms[n.xform].inv, fwd)) return false;
+    double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int corner = 0; corner < 8; ++corner) {
+        const double x = (corner & 1) ? hi[0] : lo[0], y = (corner & 2) ? hi[1] : lo[1], z = (corner & 4) ? hi[2] : lo[2];
+        for (int row = 0; row < 3; ++row) {
+            const double v = fwd[row * 4] * x + fwd[row * 4 + 1] * y + fwd[row * 4 + 2] * z + fwd[row * 4 + 3];
+            bmin[row] = std::fmin(bmin[row], v);
+            bmax[row] = std::fmax(bmax[row], v);
+        }
+    }
+    double size = 0.0, reach = 0.0, smin = INFINITY, smax = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        size = std::fmax(size, bmax[k] - bmin[k]);
+        reach = std::fmax(reach, std::fmax(std::fabs(bmin[k]), std::fabs(bmax[k])));
+        const double col = std::sqrt(fwd[k] * fwd[k] + fwd[4 + k] * fwd[4 + k] + fwd[8 + k] * fwd[8 + k]);
+        smin = std::fmin(smin, col);
+        smax = std::fmax(smax, col);
+    }
+    if (!std::isfinite(size) || !std::isfinite(reach) || !(smin > 0.0)) return false;
+    // A ray origin at distance D is at most D / smin from the leaf in object space, where the
+    // quadratic's discriminant carries an error of about 10 eps (D / smin)^2; a line that misses
+    // the unit shape by less than half of that can still be reported as a hit, which is up to
+    // smax times as far in this space.  10^-9 leaves six orders of magnitude over eps.
+    const double far_term = 1e-9 * smax / (smin * smin);
+    out.kind = T_CULL;
+    out.r0 = 1e-6 * (size + reach) + 2.0 * far_term * reach * reach;  // |o - c|^2 <= 2 |o|^2 + 2 reach^2
+    out.r1 = 2.0 * far_term;
+    if (!std::isfinite(out.r0) || !std::isfinite(out.r1)) return false;
+    for (int k = 0; k < 3; ++k) {
+        out.p[k] = bmin[k];
+        out.p[3 + k] = bmax[k];
+    }
+    return true;
+}
+
 // Lays the node table out as traversal records (see TRec).
 std::vector<TRec> build_records(const rt_scene_desc* d) {
     std::vector<TRec> out;
@@ -1261,7 +1374,8 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
         const rt_node& n = d->nodes[i];
         first[i] = count;
         const bool own_payload = n.type == RT_GROUP || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
-        count += (n.xform >= 0 && own_payload) ? 2 : 1;
+        TRec probe{};
+        count += ((n.xform >= 0 && own_payload) || cull_record(d, n, probe)) ? 2 : 1;
     }
     first[d->n_nodes] = count;
     out.reserve(count);
@@ -1280,9 +1394,16 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
             out.push_back(x);
             flags |= T_OWN_XFORM;
             r.ctx = first[i];  // the node itself is tested in its own space
-        } else if (n.xform >= 0) {
-            flags |= T_HAS_INV;
-            std::memcpy(r.p, d->xforms[n.xform].inv, sizeof r.p);
+        } else {
+            TRec c = r;
+            if (cull_record(d, n, c)) {
+                c.skip = first[i] + 2;  // past the leaf
+                out.push_back(c);
+            }
+            if (n.xform >= 0) {
+                flags |= T_HAS_INV;
+                std::memcpy(r.p, d->xforms[n.xform].inv, sizeof r.p);
+            }
         }
         r.kind = n.type | flags;
         if (n.type == RT_GROUP) {

@@ -202,3 +202,61 @@ def test_random_scene(host, orc, seed):
     err = np.abs(img[finite] - ref[finite])
     scale = np.maximum(1.0, np.abs(ref[finite]))
     assert (err / scale).max() <= 1e-9, "seed %d: max rel err %.3e" % (seed, (err / scale).max())
+
+
+# ---- conservative culling must never change a result ---------------------------------------------------
+def quadric_world(api, seed):
+    """Finite spheres, cubes and cylinders (the leaves the device skips through padded boxes) under
+    stretched, sheared and tiny transforms, some transparent so that the container bookkeeping runs."""
+    rng = np.random.default_rng(1000 + seed)
+    M = api.Matrix
+    objects = []
+    for _ in range(12):
+        t = M.translation(*rng.uniform(-4, 4, 3))
+        t = t * M.rotation_y(rng.uniform(-3, 3)) * M.rotation_x(rng.uniform(-3, 3))
+        t = t * M.scaling(*(10.0 ** rng.uniform(-1.5, 0.5, 3)))
+        if rng.random() < 0.4:
+            t = t * M.shearing(*rng.uniform(-0.5, 0.5, 6))
+        transp = float(rng.choice([0.0, 0.0, 0.8]))
+        m = api.Phong(api.Solid(api.Color(*rng.uniform(0, 1, 3))), 0.2, 0.7, 0.3, 50.0,
+                      float(rng.choice([0.0, 0.4])), transp, float(rng.uniform(1.0, 2.0)))
+        k = rng.integers(0, 3)
+        if k == 0:
+            objects.append(api.Sphere(t, m, True))
+        elif k == 1:
+            objects.append(api.Cube(t, m, True))
+        else:
+            lo, hi = sorted(rng.uniform(-1.5, 1.5, 2))
+            objects.append(api.Cylinder(t, m, True, float(lo), float(hi), bool(rng.random() < 0.5)))
+    lights = [api.PointLight(api.point(*rng.uniform(-12, 12, 3)), api.Color.white()) for _ in range(2)]
+    return api.World(objects, lights)
+
+
+@pytest.mark.parametrize("seed", list(range(8)))
+def test_culling_is_conservative(host, orc, seed):
+    """Rays from 10 to 10^7 units away aimed at and just past the silhouettes of the objects: the
+    padded boxes must keep every ray the exact arithmetic counts as a hit, including the false hits
+    that cancellation produces for far origins."""
+    rng = np.random.default_rng(seed)
+    origins, dirs = [], []
+    for dist in (10.0, 1e3, 1e5, 1e7):
+        for _ in range(300):
+            target = rng.uniform(-5, 5, 3)
+            o = rng.normal(size=3)
+            o = o / np.linalg.norm(o) * dist
+            if rng.random() < 0.3:
+                o[rng.integers(0, 3)] = 0.0  # axis-parallel planes of the boxes
+            d = target - o
+            if rng.random() < 0.2:
+                d[rng.integers(0, 3)] = 0.0  # a direction component the slab tests treat as parallel
+            origins.append(o)
+            dirs.append(d / np.linalg.norm(d))
+    o = np.array(origins)
+    d = np.array(dirs)
+    got = host.color_at(quadric_world(host, seed), o, d, remaining=3)
+    ref = orc.color_at_batch(quadric_world(orc, seed), o, d, remaining=3)
+    finite = np.isfinite(ref)
+    assert np.array_equal(np.isfinite(got), finite)
+    err = np.abs(got[finite] - ref[finite]) / np.maximum(1.0, np.abs(ref[finite]))
+    assert err.max() <= 1e-9, "seed %d: max rel err %.3e" % (seed, err.max())
+    assert (ref[finite] != 0.0).any()
