@@ -300,7 +300,8 @@ enum { MODE_CLOSEST = 0, MODE_CLOSEST_TRACK = 1, MODE_SHADOW = 2 };
 // at its first intersection in (0, limit) (any such intersection implies the nearest one is too).
 // XF: the scene has transformed groups or triangles (T_XFORM records); without them the ray never
 // changes space between records and the world-space copy is not kept.
-template <int MODE, bool XF>
+// CULL: the scene has T_CULL records.
+template <int MODE, bool XF, bool CULL>
 DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
     constexpr bool TRACK = MODE == MODE_CLOSEST_TRACK;
     h.found = false;
@@ -324,7 +325,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     int cur_ctx = -1;
     V3 co = wo, cd = wd;  // the ray in the space of the transformed group `cur_ctx`
     V3 cy = reciprocal(cd);  // exact reciprocals of cd, used by the fast slab test
-    double coo = dot(co, co);  // scales the padding of T_CULL boxes
+    double coo = CULL ? dot(co, co) : 0.0;  // scales the padding of T_CULL boxes
     bool cfin = all_axes_finite(cd);
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
 
@@ -357,7 +358,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             cd = wd;
             chain_ray(S, ctx, co, cd);
             cy = reciprocal(cd);
-            coo = dot(co, co);
+            if (CULL) coo = dot(co, co);
             cfin = all_axes_finite(cd);
             cur_ctx = ctx;
         }
@@ -369,13 +370,13 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             co = to;
             cd = td;
             cy = reciprocal(cd);
-            coo = dot(co, co);
+            if (CULL) coo = dot(co, co);
             cfin = all_axes_finite(cd);
             cur_ctx = i;
             i = i + 1;
             continue;
         }
-        if (type == T_CULL) {
+        if (CULL && type == T_CULL) {
             // Box p[0..5] grown by r0 + r1 * |origin|^2: r0 covers the rounding of this test, the
             // second term the rounding of the leaf's own quadratic for far-away origins (its
             // discriminant loses about eps * |origin|^2, which can turn a near miss into a hit).
@@ -754,7 +755,7 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
 #define RT_MIN_WAVES 5
 #endif
 #ifndef RT_MIN_WAVES_XF
-#define RT_MIN_WAVES_XF 4
+#define RT_MIN_WAVES_XF 5
 #endif
 #ifndef RT_BLOCK_WAVES
 #define RT_BLOCK_WAVES 1  // wavefronts (8x8 tiles) per workgroup; one gives the dispatcher the finest grain
@@ -777,7 +778,7 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, i
     local_y = lty * RT_TILE + (lane >> 3);
 }
 
-template <bool TRACK, bool XF>
+template <bool TRACK, bool XF, bool CULL>
 __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
@@ -832,7 +833,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
         unsigned long long pt = __builtin_amdgcn_s_memtime();
 #endif
-        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST, XF>(S, pending, ro, rd, 0.0, h);
+        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST, XF, CULL>(S, pending, ro, rd, 0.0, h);
 #ifdef RT_PROFILE
         prof_closest += __builtin_amdgcn_s_memtime() - pt;
         prof_visits += h.visits;
@@ -979,7 +980,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
             unsigned long long ps = __builtin_amdgcn_s_memtime();
 #endif
-            trace<MODE_SHADOW, XF>(S, shade, over, lightv, distance, sh);
+            trace<MODE_SHADOW, XF, CULL>(S, shade, over, lightv, distance, sh);
 #ifdef RT_PROFILE
             prof_shadow += __builtin_amdgcn_s_memtime() - ps;
             prof_visits += sh.visits;
@@ -1167,6 +1168,7 @@ struct rt_scene {
     DevScene dev{};
     bool any_transparent = false;
     bool any_xform = false;  // the traversal records include T_XFORM entries
+    bool any_cull = false;   // ... and T_CULL entries
     std::vector<void*> allocations;
     unsigned long long* d_counters = nullptr;
     double* d_frame = nullptr;  // staging for the synchronous entry points
@@ -1496,8 +1498,12 @@ int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipSt
     HIP_TRY(hipMemsetAsync(s->d_counters, 0, COUNTER_SHARDS * 16 * sizeof(unsigned long long), stream));
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (blocks > 0) {
-        auto kernel = s->any_transparent ? (s->any_xform ? rt_kernel<true, true> : rt_kernel<true, false>)
-                                         : (s->any_xform ? rt_kernel<false, true> : rt_kernel<false, false>);
+        using Kernel = void (*)(DevScene, DevJob, double*, unsigned long long*);
+        static const Kernel kernels[8] = {rt_kernel<false, false, false>, rt_kernel<false, false, true>,
+                                          rt_kernel<false, true, false>,  rt_kernel<false, true, true>,
+                                          rt_kernel<true, false, false>,  rt_kernel<true, false, true>,
+                                          rt_kernel<true, true, false>,   rt_kernel<true, true, true>};
+        Kernel kernel = kernels[(s->any_transparent ? 4 : 0) | (s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, s->d_counters);
         HIP_TRY(hipGetLastError());
     }
@@ -1575,6 +1581,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         s->dev.n_trav = (int)recs.size();
         for (const TRec& r : recs)
             if ((r.kind & 0xff) == T_XFORM) s->any_xform = true;
+            else if ((r.kind & 0xff) == T_CULL) s->any_cull = true;
     }
     if ((rc = upload(s, d->nodes, d->n_nodes, &s->dev.nodes)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms)) != RT_OK) return cleanup(rc);
