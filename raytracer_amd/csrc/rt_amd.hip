@@ -727,12 +727,10 @@ DI double schlick(double cosv, double n1, double n2) {
 // (World::shade_hit, world.rs:162-196).
 struct Frame {
     double surf[RT_MAX_LIGHTS][3];  // surface colour per light, in light order
-    double refl[3];                 // reflected colour * reflective
-    double rray[6];                 // pending refraction ray (under_point, direction)
-    double first[3];                // direction of the reflection ray (origin: over_point)
-    double k;                       // Schlick reflectance
-    double transparency;
-    double reflective;
+    double refl[3];                 // reflected colour * reflective (written once it is known)
+    double rray[6];                 // pending refraction ray (under_point, direction); only with a refraction
+    double k;                       // Schlick reflectance; only when state bit2 is set
+    int node;                       // the hit leaf: its reflective / transparency are re-read on return
     int state;                      // bit0: waiting for refraction (else reflection); bit1: refraction still to trace; bit2: use Schlick
 };
 
@@ -940,25 +938,26 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
                 if (use_k && (want_refl || want_refr)) kk = schlick(cos_i, n1, n2);
             }
             if (want_refl || want_refr) {
+                // Only what the return path cannot recompute is written: most frames belong to
+                // plain reflections and hold the surface colours, the node and the state.
                 Frame& f = frames[sp];
-                V3 under = point - (normalv * RT_EPS);
-                V3 reflectv = reflect(rd, normalv);
-                f.k = kk;
-                f.reflective = refl_c;
-                f.transparency = transp;
-                f.first[0] = reflectv.x;
-                f.first[1] = reflectv.y;
-                f.first[2] = reflectv.z;
-                f.rray[0] = under.x;
-                f.rray[1] = under.y;
-                f.rray[2] = under.z;
-                f.rray[3] = refr_dir.x;
-                f.rray[4] = refr_dir.y;
-                f.rray[5] = refr_dir.z;
-                f.refl[0] = 0.0;
-                f.refl[1] = 0.0;
-                f.refl[2] = 0.0;
+                f.node = node;
                 f.state = want_refl ? ((want_refr ? 2 : 0) | (use_k ? 4 : 0)) : (1 | (use_k ? 4 : 0));
+                if (use_k) f.k = kk;
+                if (want_refr) {
+                    V3 under = point - (normalv * RT_EPS);
+                    f.rray[0] = under.x;
+                    f.rray[1] = under.y;
+                    f.rray[2] = under.z;
+                    f.rray[3] = refr_dir.x;
+                    f.rray[4] = refr_dir.y;
+                    f.rray[5] = refr_dir.z;
+                    if (!want_refl) {
+                        f.refl[0] = 0.0;
+                        f.refl[1] = 0.0;
+                        f.refl[2] = 0.0;
+                    }
+                }
             }
             // Pattern::pattern_at_shape at over_point (phong.rs:68, pattern.rs:8-14)
             if (sflags & S_SOLID) {
@@ -1027,8 +1026,8 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
             if (has_children) {
                 const Frame& f = frames[sp];
                 if (want_refl) {
+                    rd = reflect(rd, normalv);  // reflectv (world.rs:92)
                     ro = over;
-                    rd = mk(f.first[0], f.first[1], f.first[2]);
                     ++n_reflect;
                 } else {
                     ro = mk(f.rray[0], f.rray[1], f.rray[2]);
@@ -1049,7 +1048,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
                 Frame& f = frames[sp - 1];
                 if ((f.state & 1) == 0) {
                     // the reflected colour arrived (world.rs:228-230)
-                    V3 refl = value * f.reflective;
+                    V3 refl = value * S.shade[f.node].refl;
                     if (f.state & 2) {
                         f.refl[0] = refl.x;
                         f.refl[1] = refl.y;
@@ -1063,7 +1062,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
                     value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
                 } else {
                     // the refracted colour arrived (world.rs:274)
-                    V3 refr = value * f.transparency;
+                    V3 refr = value * S.shade[f.node].transp;
                     value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
                 }
                 --sp;
