@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-depth", type=int, default=5, help="diagnostic: `remaining` of primary rays (the metric uses 5)")
+    ap.add_argument("--gather", choices=["u8", "f64"], default="u8",
+                    help="N > 1: what rank 0 collects per frame: the clamped bytes the PPM prints (default) or the f64 colours")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
     args = ap.parse_args()
 
     import torch
@@ -121,22 +124,32 @@ def main():
     world, cam = make_world(host), make_camera(host, W, H)
     scene = host.scene_handle(world, device=local_rank)
     rows = host.local_rows(H, rank, world_size)
-    local = torch.empty((rows, W, 3), dtype=torch.float64, device=dev)
+    u8 = world_size > 1 and args.gather == "u8"
+    dtype = torch.uint8 if u8 else torch.float64
+    buffers = [torch.empty((rows, W, 3), dtype=dtype, device=dev) for _ in range(2 if world_size > 1 else 1)]
 
-    from raytracer_amd.distributed import FrameGather
-    gather = FrameGather(host, W, H, rank, world_size, dev) if world_size > 1 else None
+    from raytracer_amd.distributed import FrameGather, OverlappedGather
+    gather = FrameGather(host, W, H, rank, world_size, dev, dtype=dtype) if world_size > 1 else None
+    pipe = OverlappedGather(gather, buffers) if gather is not None and not args.no_overlap else None
+
+    def render(buf):
+        stream = torch.cuda.current_stream().cuda_stream
+        host.render_device(world, cam, buf.data_ptr(), stream=stream, device=local_rank, rank=rank,
+                           world_size=world_size, max_depth=args.max_depth, u8=u8)
 
     def step():
-        stream = torch.cuda.current_stream().cuda_stream
-        host.render_device(world, cam, local.data_ptr(), stream=stream, device=local_rank, rank=rank,
-                           world_size=world_size, max_depth=args.max_depth)
-        if gather is not None:
-            gather(local)  # RCCL send/recv of the compact tile buffers to rank 0, rows into frame order
+        if pipe is not None:
+            pipe.step(render)  # RCCL send/recv of frame k's tile buffers overlaps the render of frame k + 1
+        else:
+            render(buffers[0])
+            if gather is not None:
+                gather(buffers[0])  # RCCL send/recv of the compact tile buffers to rank 0, rows into frame order
 
     def sync():
+        torch.cuda.synchronize()  # all streams of this device, the gather's side stream included
         if world_size > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -185,7 +198,11 @@ def main():
             "config": {
                 "workload": "%s scene (src/lib.rs build_world), %dx%d, depth 5" % (args.workload, W, H),
                 "rays_per_frame": int(rays),
-                "partition": "cyclic 8-row tiles over %d rank(s)%s" % (world_size, ", RCCL gather to rank 0" if world_size > 1 else ""),
+                "partition": "cyclic 8-row tiles over %d rank(s)%s" % (
+                    world_size,
+                    ", RCCL gather of %s rows to rank 0%s" % (
+                        "clamped u8" if u8 else "f64", "" if args.no_overlap else ", overlapped with the next frame's render")
+                    if world_size > 1 else ""),
             },
             "kernel_ms": kernel_ms,
         }

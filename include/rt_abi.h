@@ -151,6 +151,15 @@ int rt_render_device(rt_scene* scene, const rt_camera* camera, const rt_params* 
 /* Same, but synchronous into HOST memory; fills stats when not NULL. */
 int rt_render(rt_scene* scene, const rt_camera* camera, const rt_params* params, double* rgb_out,
               rt_stats* stats);
+/* render followed by Canvas::clamp on every channel (src/canvas.rs:50-60: 255*c saturated to
+ * [0, 255] and rounded up, NaN -> 0): the values Canvas::to_ppm prints (src/canvas.rs:62-94),
+ * 3 bytes per pixel in the same pixel order, without the f64 frame ever leaving the device.
+ * d_rgb8 is DEVICE memory of rt_local_rows * width * 3 bytes. */
+int rt_render_device_u8(rt_scene* scene, const rt_camera* camera, const rt_params* params,
+                        uint8_t* d_rgb8, void* hip_stream);
+/* Same, but synchronous into HOST memory; fills stats when not NULL. */
+int rt_render_u8(rt_scene* scene, const rt_camera* camera, const rt_params* params, uint8_t* rgb8_out,
+                 rt_stats* stats);
 /* Replaces World::color_at (src/scene/world.rs:198-212) for n rays given as packed xyz origins
  * and directions in host memory; writes n*3 doubles to host memory. */
 int rt_color_at(rt_scene* scene, int64_t n, const double* origins, const double* directions,

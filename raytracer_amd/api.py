@@ -32,9 +32,12 @@ class HostApi(Api):
             "world_scene": (C.c_int, [c_i64, C.c_int, P(C.c_void_p)]),
             "render": (C.c_int, [c_i64, c_i64, C.c_int, P(abi.rt_params), c_dp, P(abi.rt_stats)]),
             "render_device": (C.c_int, [c_i64, c_i64, C.c_int, P(abi.rt_params), C.c_void_p, C.c_void_p]),
+            "render_u8": (C.c_int, [c_i64, c_i64, C.c_int, P(abi.rt_params), P(C.c_uint8), P(abi.rt_stats)]),
+            "render_device_u8": (C.c_int, [c_i64, c_i64, C.c_int, P(abi.rt_params), C.c_void_p, C.c_void_p]),
             "color_at": (C.c_int, [c_i64, C.c_int, c_i64, c_dp, c_dp, C.c_int, c_dp, P(abi.rt_stats)]),
             "clamp_u8": (C.c_int, [c_d]),
             "to_ppm": (c_i64, [c_dp, c_i64, c_i64]),
+            "to_ppm_u8": (c_i64, [P(C.c_uint8), c_i64, c_i64]),
             "ppm_copy": (None, [C.c_char_p]),
         }
         for name, (res, args) in sig.items():
@@ -97,11 +100,27 @@ class HostApi(Api):
                                       C.byref(st)))
         return (img, st) if stats else img
 
-    def render_device(self, world, camera, d_ptr, stream=None, max_depth=5, device=0, rank=0, world_size=1):
-        """Asynchronous render into device memory at address d_ptr (e.g. a torch tensor's data_ptr)."""
+    def render_u8(self, world, camera, max_depth=5, device=0, rank=0, world_size=1, stats=False):
+        """render followed by Canvas::clamp (src/window/canvas.rs:50-60) on the GPU -> uint8 array
+        (rows, W, 3): the values to_ppm prints."""
         prm = abi.rt_params(max_depth, rank, world_size, 0)
-        self._check(self._f("render_device")(world.h, camera.h, device, C.byref(prm), C.c_void_p(d_ptr),
-                                             C.c_void_p(stream or 0)))
+        W, H = camera.width(), camera.height()
+        rows = self.abi.rt_local_rows(H, C.byref(prm))
+        if rows < 0:
+            raise abi.RtError(abi.RT_ERR_INVALID, self.abi.rt_last_error().decode())
+        img = np.empty((rows, W, 3), dtype=np.uint8)
+        st = abi.rt_stats()
+        self._check(self._f("render_u8")(world.h, camera.h, device, C.byref(prm),
+                                         img.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(st)))
+        return (img, st) if stats else img
+
+    def render_device(self, world, camera, d_ptr, stream=None, max_depth=5, device=0, rank=0, world_size=1,
+                      u8=False):
+        """Asynchronous render into device memory at address d_ptr (e.g. a torch tensor's data_ptr):
+        3 doubles per pixel, or with u8=True the 3 clamped bytes per pixel."""
+        prm = abi.rt_params(max_depth, rank, world_size, 0)
+        self._check(self._f("render_device_u8" if u8 else "render_device")(
+            world.h, camera.h, device, C.byref(prm), C.c_void_p(d_ptr), C.c_void_p(stream or 0)))
 
     def color_at(self, world, origins, directions, remaining=5, device=0, stats=False):
         """World::color_at (src/scene/world.rs:198-212) for a batch of rays on the GPU."""
@@ -130,10 +149,15 @@ class HostApi(Api):
         return self._f("clamp_u8")(float(v))
 
     def to_ppm(self, img):
-        """Canvas::to_ppm (src/window/canvas.rs:62-94) for an (H, W, 3) float64 image."""
-        img = np.ascontiguousarray(img, dtype=np.float64)
+        """Canvas::to_ppm (src/window/canvas.rs:62-94) for an (H, W, 3) float64 image, or for a
+        uint8 image that already holds the clamped values."""
         h, w = img.shape[:2]
-        n = self._f("to_ppm")(img.ctypes.data_as(c_dp), w, h)
+        if img.dtype == np.uint8:
+            img = np.ascontiguousarray(img)
+            n = self._f("to_ppm_u8")(img.ctypes.data_as(C.POINTER(C.c_uint8)), w, h)
+        else:
+            img = np.ascontiguousarray(img, dtype=np.float64)
+            n = self._f("to_ppm")(img.ctypes.data_as(c_dp), w, h)
         buf = C.create_string_buffer(n)
         self._f("ppm_copy")(buf)
         return buf.raw[:n]

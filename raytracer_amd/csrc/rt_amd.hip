@@ -107,7 +107,8 @@ struct DevJob {
     int rank, world_size, tiles_x, local_tile_rows;
     int max_depth;
     int xcd_remap;
-    int wide_stores;  // output base is 16-byte aligned and the width is even
+    int wide_stores;  // f64 output: base 16-byte aligned and even width; u8 output: base 4-byte aligned and width % 4 == 0
+    int out_u8;       // the output is 3 bytes per pixel, quantised like Canvas::clamp, instead of 3 doubles
     // ray-list mode (rt_color_at)
     long long n_rays;
     const double* ray_o;
@@ -723,6 +724,15 @@ DI double schlick(double cosv, double n1, double n2) {
     return r0 + (1.0 - r0) * m5;
 }
 
+// Canvas::clamp (canvas.rs:50-60): 255 * c, saturated to [0, 255], rounded up; NaN gives 0 like
+// Rust's saturating `as u8`.
+DI unsigned clamp_u8(double c) {
+    double x = 255.0 * c;
+    if (x > 255.0) return 255u;
+    if (!(x >= 0.0)) return 0u;
+    return (unsigned)ceil(x);
+}
+
 // One suspended color_at call that is waiting for its reflected / refracted colour
 // (World::shade_hit, world.rs:162-196).
 struct Frame {
@@ -825,6 +835,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
     unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long prof_closest = 0, prof_shadow = 0, prof_visits = 0, prof_traces = 0, prof_rounds = 0;
+    unsigned long long prof_prepare = 0, prof_light = 0, prof_return = 0;
 #endif
     while (__ballot(pending) != 0ull) {
         Hit h;
@@ -967,6 +978,10 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
             }
         }
         const bool has_children = want_refl || want_refr;
+#ifdef RT_PROFILE
+        prof_prepare += __builtin_amdgcn_s_memtime() - pt;  // includes the closest-hit trace; subtract closest_cycles
+        unsigned long long pl0 = __builtin_amdgcn_s_memtime();
+#endif
 
         // ---- per light: World::is_shadowed + Phong::lighting (world.rs:304-326, phong.rs:59-116)
         V3 acc = mk(0.0, 0.0, 0.0);
@@ -1019,6 +1034,10 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
             }
         }
 
+#ifdef RT_PROFILE
+        prof_light += __builtin_amdgcn_s_memtime() - pl0;  // includes the shadow traces; subtract shadow_cycles
+        unsigned long long pr0 = __builtin_amdgcn_s_memtime();
+#endif
         // ---- suspend, or return the colour up the stack ----------------------------------------
         if (pending) {
             V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
@@ -1068,6 +1087,9 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
                 --sp;
             }
         }
+#ifdef RT_PROFILE
+        prof_return += __builtin_amdgcn_s_memtime() - pr0;
+#endif
     }
 
     // ---- write the tile ------------------------------------------------------------------------
@@ -1085,7 +1107,30 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
         out_index = (long long)local_y * J.width + px;
     }
     const bool whole_tile = J.wide_stores && __ballot(valid) == ~0ull;
-    if (whole_tile) {
+    if (J.out_u8) {
+        // 24 bytes per tile row: the lanes' bytes are packed in LDS and 48 lanes store one dword each.
+        __shared__ unsigned tile8_lds[RT_BLOCK_WAVES][48];
+        unsigned char* const t8 = reinterpret_cast<unsigned char*>(tile8_lds[wave]);
+        unsigned char* const out8 = reinterpret_cast<unsigned char*>(out);
+        const unsigned r = clamp_u8(my_pixel[0]), g = clamp_u8(my_pixel[1]), b = clamp_u8(my_pixel[2]);
+        if (whole_tile) {
+            t8[lane * 3] = (unsigned char)r;
+            t8[lane * 3 + 1] = (unsigned char)g;
+            t8[lane * 3 + 2] = (unsigned char)b;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (lane < 48) {
+                const int row = lane / 6, piece = lane % 6;
+                const long long origin = out_index - (lane & 7) - (long long)(lane >> 3) * J.width;  // this lane's tile origin
+                *reinterpret_cast<unsigned*>(out8 + (origin + (long long)row * J.width) * 3 + piece * 4) =
+                    tile8_lds[wave][lane];
+            }
+        } else if (valid) {
+            out8[out_index * 3] = (unsigned char)r;
+            out8[out_index * 3 + 1] = (unsigned char)g;
+            out8[out_index * 3 + 2] = (unsigned char)b;
+        }
+    } else if (whole_tile) {
         const double* t = tile_lds[wave];
         // rows of the tile are 8 pixels apart in the lane order, so the LDS image is already
         // [row][192 bytes]; piece c (16 bytes) belongs to row c / 12, byte offset (c % 12) * 16
@@ -1102,6 +1147,9 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
         out[out_index * 3 + 1] = my_pixel[1];
         out[out_index * 3 + 2] = my_pixel[2];
     }
+    // Ray statistics: one atomic per wavefront and counter, spread over COUNTER_SHARDS copies so
+    // that the 10^5 wavefronts of a frame do not serialise on four words.
+    counters += 16 * ((blockIdx.x * (unsigned)RT_BLOCK_WAVES + (unsigned)wave) % COUNTER_SHARDS);
 #ifdef RT_PROFILE
     if (lane == 0) {
         atomicAdd(&counters[4], __builtin_amdgcn_s_memtime() - prof_t0);
@@ -1111,15 +1159,10 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
         atomicAdd(&counters[8], prof_traces);
         atomicAdd(&counters[9], prof_rounds);
         atomicAdd(&counters[10], 1ull);
-        atomicMax(&counters[11], __builtin_amdgcn_s_memtime() - prof_t0);
-        atomicMax(&counters[12], prof_rounds);
-        // histogram of wave durations in 2^k-cycle buckets is not kept; the maximum is what bounds the tail
+        atomicAdd(&counters[11], prof_prepare);
+        atomicAdd(&counters[12], prof_light);
+        atomicAdd(&counters[13], prof_return);
     }
-#endif
-    // Ray statistics: one atomic per wavefront and counter, spread over COUNTER_SHARDS copies so
-    // that the 10^5 wavefronts of a frame do not serialise on four words.
-#ifndef RT_PROFILE
-    counters += 16 * ((blockIdx.x * (unsigned)RT_BLOCK_WAVES + (unsigned)wave) % COUNTER_SHARDS);
 #endif
     unsigned c[4] = {n_primary, n_shadow, n_reflect, n_refract};
 #pragma unroll
@@ -1528,8 +1571,8 @@ int fill_stats(rt_scene* s, rt_stats* st) {
 #ifdef RT_PROFILE
     {
         const unsigned long long* pc = c;
-        fprintf(stderr, "RT_PROFILE waves=%llu wave_cycles=%llu closest_cycles=%llu shadow_cycles=%llu visits=%llu traces=%llu rounds=%llu max_wave_cycles=%llu max_rounds=%llu\n",
-                pc[10], pc[4], pc[5], pc[6], pc[7], pc[8], pc[9], pc[11], pc[12]);
+        fprintf(stderr, "RT_PROFILE waves=%llu wave_cycles=%llu closest_cycles=%llu shadow_cycles=%llu visits=%llu traces=%llu rounds=%llu prepare_cycles=%llu lighting_cycles=%llu return_cycles=%llu\n",
+                pc[10], pc[4], pc[5], pc[6], pc[7], pc[8], pc[9], pc[11], pc[12], pc[13]);
     }
 #endif
     if (s->launches > 0) {
@@ -1645,7 +1688,8 @@ int64_t rt_global_row(int64_t local_row, const rt_params* p) {
     return (lt * p->world_size + p->rank) * RT_TILE + local_row % RT_TILE;
 }
 
-int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* d_rgb, void* hip_stream) {
+static int render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, void* d_rgb, bool out_u8,
+                         void* hip_stream) {
     if (!s || !cam) return fail(RT_ERR_INVALID, "null scene or camera");
     int rc = check_params(prm);
     if (rc != RT_OK) return rc;
@@ -1668,21 +1712,34 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, do
         job.xcd_remap = e ? atoi(e) : 0;
     }
     job.n_rays = 0;
-    job.wide_stores = ((reinterpret_cast<uintptr_t>(d_rgb) & 15) == 0 && (cam->width & 1) == 0) ? 1 : 0;
+    job.out_u8 = out_u8 ? 1 : 0;
+    if (out_u8)
+        job.wide_stores = ((reinterpret_cast<uintptr_t>(d_rgb) & 3) == 0 && (cam->width & 3) == 0) ? 1 : 0;
+    else
+        job.wide_stores = ((reinterpret_cast<uintptr_t>(d_rgb) & 15) == 0 && (cam->width & 1) == 0) ? 1 : 0;
     long long tiles = (long long)job.tiles_x * job.local_tile_rows;
     if (tiles > 0 && !d_rgb) return fail(RT_ERR_INVALID, "null output buffer");
     long long blocks = (tiles + RT_BLOCK_WAVES - 1) / RT_BLOCK_WAVES;
     if (blocks > 0x7fffffffLL) return fail(RT_ERR_LIMIT, "frame too large for one launch");
-    return launch(s, job, (unsigned)blocks, d_rgb, (hipStream_t)hip_stream);
+    return launch(s, job, (unsigned)blocks, (double*)d_rgb, (hipStream_t)hip_stream);
 }
 
-int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* rgb_out, rt_stats* stats) {
+int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* d_rgb, void* hip_stream) {
+    return render_device(s, cam, prm, d_rgb, false, hip_stream);
+}
+
+int rt_render_device_u8(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint8_t* d_rgb8, void* hip_stream) {
+    return render_device(s, cam, prm, d_rgb8, true, hip_stream);
+}
+
+static int render_host(rt_scene* s, const rt_camera* cam, const rt_params* prm, void* out, bool out_u8,
+                       rt_stats* stats) {
     if (!s || !cam) return fail(RT_ERR_INVALID, "null scene or camera");
     int rc = check_params(prm);
     if (rc != RT_OK) return rc;
     int64_t rows = rt_local_rows(cam->height, prm);
-    size_t bytes = (size_t)rows * (size_t)cam->width * 3 * sizeof(double);
-    if (bytes && !rgb_out) return fail(RT_ERR_INVALID, "null output buffer");
+    size_t bytes = (size_t)rows * (size_t)cam->width * 3 * (out_u8 ? 1 : sizeof(double));
+    if (bytes && !out) return fail(RT_ERR_INVALID, "null output buffer");
     HIP_TRY(hipSetDevice(s->device));
     if (bytes > s->frame_bytes) {
         if (s->d_frame) HIP_TRY(hipFree(s->d_frame));
@@ -1693,11 +1750,19 @@ int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* r
         s->d_frame = (double*)p;
         s->frame_bytes = bytes;
     }
-    rc = rt_render_device(s, cam, prm, s->d_frame, nullptr);
+    rc = render_device(s, cam, prm, s->d_frame, out_u8, nullptr);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipStreamSynchronize(nullptr));
-    if (bytes) HIP_TRY(hipMemcpy(rgb_out, s->d_frame, bytes, hipMemcpyDeviceToHost));
+    if (bytes) HIP_TRY(hipMemcpy(out, s->d_frame, bytes, hipMemcpyDeviceToHost));
     return fill_stats(s, stats);
+}
+
+int rt_render_u8(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint8_t* rgb8_out, rt_stats* stats) {
+    return render_host(s, cam, prm, rgb8_out, true, stats);
+}
+
+int rt_render(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* rgb_out, rt_stats* stats) {
+    return render_host(s, cam, prm, rgb_out, false, stats);
 }
 
 int rt_color_at(rt_scene* s, int64_t n, const double* origins, const double* directions, int32_t remaining,

@@ -6,6 +6,11 @@ the reference does through its channel (src/lib.rs:102-104, 121-126): every rank
 tile buffer to rank 0, which places the rows in frame order.  With the nccl backend that is a grouped
 send/recv over RCCL; each peer uses its own xGMI link to rank 0.  The same code runs on CPU tensors
 with gloo, which is how it is tested without GPUs.
+
+The buffers hold either the f64 colours (what `render` returns, 24 bytes per pixel) or the clamped
+bytes the PPM prints (3 bytes per pixel); rank 0's xGMI ingest is the shared resource, so the byte
+form moves an eighth of the data.  OverlappedGather runs the exchange of frame k on a side stream
+while frame k + 1 renders.
 """
 import numpy as np
 import torch
@@ -13,23 +18,24 @@ import torch.distributed as dist
 
 
 class FrameGather:
-    def __init__(self, host, width, height, rank, world_size, device, dst=0):
+    def __init__(self, host, width, height, rank, world_size, device, dst=0, dtype=torch.float64):
         self.rank, self.world_size, self.dst = rank, world_size, dst
+        self.dtype = dtype
         self.width, self.height = width, height
         self.rows = [host.local_rows(height, r, world_size) for r in range(world_size)]
         self.frame = None
         self.parts = None
         self.index = None
         if rank == dst:
-            self.frame = torch.empty((height, width, 3), dtype=torch.float64, device=device)
-            self.parts = [None if r == dst else torch.empty((self.rows[r], width, 3), dtype=torch.float64, device=device)
+            self.frame = torch.empty((height, width, 3), dtype=dtype, device=device)
+            self.parts = [None if r == dst else torch.empty((self.rows[r], width, 3), dtype=dtype, device=device)
                           for r in range(world_size)]
             self.index = [torch.from_numpy(np.asarray(host.global_rows(height, r, world_size), dtype=np.int64)).to(device)
                           for r in range(world_size)]
 
     def __call__(self, local):
-        """local: this rank's (rows, W, 3) float64 tensor.  Returns the full frame on rank dst."""
-        assert tuple(local.shape) == (self.rows[self.rank], self.width, 3)
+        """local: this rank's (rows, W, 3) tensor.  Returns the full frame on rank dst."""
+        assert tuple(local.shape) == (self.rows[self.rank], self.width, 3) and local.dtype == self.dtype
         if self.world_size > 1 and local.is_cuda and dist.get_backend() == "gloo":
             return self._staged(local)  # rehearsal only: gloo moves host memory
         if self.world_size > 1:
@@ -47,7 +53,7 @@ class FrameGather:
         if self.rank == self.dst:
             for r in range(self.world_size):
                 if r != self.dst and self.rows[r] > 0:
-                    tmp = torch.empty(self.parts[r].shape, dtype=torch.float64)
+                    tmp = torch.empty(self.parts[r].shape, dtype=self.dtype)
                     dist.recv(tmp, r)
                     self.parts[r].copy_(tmp)
         elif self.rows[self.rank] > 0:
@@ -62,3 +68,42 @@ class FrameGather:
             if self.rows[r] > 0:
                 self.frame.index_copy_(0, self.index[r], part)
         return self.frame
+
+
+class OverlappedGather:
+    """Double-buffered frames: the exchange of frame k runs on a side stream while the caller's
+    stream renders frame k + 1 into the other buffer.  On CPU tensors (tests) it degrades to render
+    then gather.  The frame returned by step() is complete once `wait()` has returned."""
+
+    def __init__(self, gather, buffers):
+        assert len(buffers) >= 2
+        self.gather, self.buffers, self.k = gather, buffers, 0
+        self.cuda = buffers[0].is_cuda
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=buffers[0].device)
+            self.done = [None] * len(buffers)
+
+    def step(self, render):
+        """render(buffer) enqueues the render of the next frame into `buffer` on the current stream."""
+        b = self.k % len(self.buffers)
+        self.k += 1
+        buf = self.buffers[b]
+        if not self.cuda:
+            render(buf)
+            return self.gather(buf)
+        main = torch.cuda.current_stream(buf.device)
+        if self.done[b] is not None:
+            main.wait_event(self.done[b])  # the exchange that last read this buffer
+        render(buf)
+        ready = torch.cuda.Event()
+        ready.record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(ready)
+            frame = self.gather(buf)
+            self.done[b] = torch.cuda.Event()
+            self.done[b].record(self.side)
+        return frame
+
+    def wait(self):
+        if self.cuda:
+            self.side.synchronize()

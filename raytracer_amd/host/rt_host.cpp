@@ -692,7 +692,9 @@ int clamp(double value) {
     double c = std::ceil(x);
     return (c != c) ? 0 : (int)c;
 }
-std::string to_ppm(const double* rgb, size_t w, size_t h) {
+// Canvas::to_ppm (canvas.rs:62-126) over values produced by `value(index)`, already clamped.
+template <class F>
+std::string ppm_text(size_t w, size_t h, F value) {
     std::string out;
     out.reserve(w * h * 12 + 32);
     out += "P3\n" + std::to_string(w) + " " + std::to_string(h) + "\n255\n";
@@ -700,7 +702,7 @@ std::string to_ppm(const double* rgb, size_t w, size_t h) {
     for (size_t y = 0; y < h; ++y) {
         size_t len = 0;
         for (size_t i = 0; i < w * 3; ++i) {
-            int n = std::snprintf(buf, sizeof buf, "%d", clamp(rgb[y * w * 3 + i]));
+            int n = std::snprintf(buf, sizeof buf, "%d", value(y * w * 3 + i));
             if (len + (size_t(n) + 1) >= 70) {
                 out += '\n';
                 len = 0;
@@ -719,6 +721,12 @@ std::string to_ppm(const double* rgb, size_t w, size_t h) {
         if (len > 0) out += '\n';
     }
     return out;
+}
+std::string to_ppm(const double* rgb, size_t w, size_t h) {
+    return ppm_text(w, h, [rgb](size_t i) { return clamp(rgb[i]); });
+}
+std::string to_ppm_u8(const uint8_t* rgb8, size_t w, size_t h) {
+    return ppm_text(w, h, [rgb8](size_t i) { return (int)rgb8[i]; });
 }
 
 // ---- handle registry ----------------------------------------------------------------------------------
@@ -1018,6 +1026,23 @@ int rth_render_device(int64_t w, int64_t c, int device, const rt_params* params,
     if (!camera_block(*g_reg.cameras.at(c), cam)) return RT_ERR_INVALID;
     return rt_render_device(world->scene, &cam, params, d_rgb, stream);
 }
+// The same with Canvas::clamp applied on the device: 3 bytes per pixel (canvas.rs:50-60).
+int rth_render_u8(int64_t w, int64_t c, int device, const rt_params* params, uint8_t* rgb8_out, rt_stats* stats) {
+    auto& world = g_reg.worlds.at(w);
+    int rc = ensure_scene(*world, device);
+    if (rc != RT_OK) return rc;
+    rt_camera cam;
+    if (!camera_block(*g_reg.cameras.at(c), cam)) return RT_ERR_INVALID;
+    return rt_render_u8(world->scene, &cam, params, rgb8_out, stats);
+}
+int rth_render_device_u8(int64_t w, int64_t c, int device, const rt_params* params, uint8_t* d_rgb8, void* stream) {
+    auto& world = g_reg.worlds.at(w);
+    int rc = ensure_scene(*world, device);
+    if (rc != RT_OK) return rc;
+    rt_camera cam;
+    if (!camera_block(*g_reg.cameras.at(c), cam)) return RT_ERR_INVALID;
+    return rt_render_device_u8(world->scene, &cam, params, d_rgb8, stream);
+}
 int rth_color_at(int64_t w, int device, int64_t n, const double* origins, const double* directions, int remaining,
                  double* rgb_out, rt_stats* stats) {
     auto& world = g_reg.worlds.at(w);
@@ -1030,6 +1055,10 @@ int rth_color_at(int64_t w, int device, int64_t n, const double* origins, const 
 int rth_clamp_u8(double v) { return clamp(v); }
 int64_t rth_to_ppm(const double* rgb, int64_t w, int64_t h) {
     g_ppm = to_ppm(rgb, (size_t)w, (size_t)h);
+    return (int64_t)g_ppm.size();
+}
+int64_t rth_to_ppm_u8(const uint8_t* rgb8, int64_t w, int64_t h) {
+    g_ppm = to_ppm_u8(rgb8, (size_t)w, (size_t)h);
     return (int64_t)g_ppm.size();
 }
 void rth_ppm_copy(char* dst) { std::memcpy(dst, g_ppm.data(), g_ppm.size()); }

@@ -56,3 +56,49 @@ def test_gather_reassembles_frame(tmp_path, world_size, size):
     mp.spawn(_worker, args=(world_size, _free_port(), W, H, out), nprocs=world_size, join=True)
     frame, full = np.load(out)
     assert np.array_equal(frame, full)
+
+
+def _worker_u8(rank, world_size, port, W, H, out_path):
+    """Byte frames through OverlappedGather (its CPU form): three frames in a row, each different, so
+    that a buffer mix-up between consecutive frames would show."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    try:
+        from raytracer_amd import api
+        from raytracer_amd.distributed import FrameGather, OverlappedGather
+        host = api.load()
+        rows = host.global_rows(H, rank, world_size)
+        gather = FrameGather(host, W, H, rank, world_size, torch.device("cpu"), dtype=torch.uint8)
+        bufs = [torch.empty((len(rows), W, 3), dtype=torch.uint8) for _ in range(2)]
+        pipe = OverlappedGather(gather, bufs)
+        frames = []
+        for k in range(3):
+            def render(buf, k=k):
+                # pixel (x, y, c) of frame k is a fixed function of its frame coordinates
+                yy = torch.from_numpy(rows).view(-1, 1, 1)
+                xx = torch.arange(W).view(1, -1, 1)
+                cc = torch.arange(3).view(1, 1, -1)
+                buf.copy_(((yy * 7 + xx * 3 + cc * 11 + k * 5) % 256).to(torch.uint8))
+            frame = pipe.step(render)
+            pipe.wait()
+            if rank == 0:
+                frames.append(frame.numpy().copy())
+            else:
+                assert frame is None
+        if rank == 0:
+            np.save(out_path, np.stack(frames))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size,size", [(2, (16, 37)), (3, (12, 50))])
+def test_overlapped_byte_gather(tmp_path, world_size, size):
+    W, H = size
+    out = str(tmp_path / "frames.npy")
+    mp.spawn(_worker_u8, args=(world_size, _free_port(), W, H, out), nprocs=world_size, join=True)
+    frames = np.load(out)
+    yy, xx, cc = np.meshgrid(np.arange(H), np.arange(W), np.arange(3), indexing="ij")
+    for k in range(3):
+        assert np.array_equal(frames[k], ((yy * 7 + xx * 3 + cc * 11 + k * 5) % 256).astype(np.uint8))

@@ -118,3 +118,54 @@ def test_division_by_reciprocal_is_exact(host):
     bad = np.flatnonzero(fast.view(np.uint64) != ieee.view(np.uint64))
     bad = bad[~((fast[bad] == 0) & (ieee[bad] == 0))]  # signed zeros aside
     assert bad.size == 0, (a[bad[:5]], d[bad[:5]], fast[bad[:5]], ieee[bad[:5]])
+
+
+@pytest.mark.parametrize("name,size", [
+    ("default", (200, 120)),   # width % 4 == 0: dword stores of whole tile rows
+    ("default", (102, 67)),    # even width, ragged tiles: byte stores
+    ("default", (101, 50)),    # odd width
+    ("glass", (160, 88)),
+])
+def test_render_u8_is_clamp_of_render(host, orc, name, size):
+    """rt_render_u8 = Canvas::clamp (canvas.rs:50-60) of rt_render, value for value, and the PPM
+    text made from the bytes equals the one made from the colours."""
+    W, H = size
+    mw, mc = scenes.WORKLOADS[name]
+    img = host.render(mw(host), mc(host, W, H))
+    img8 = host.render_u8(mw(host), mc(host, W, H))
+    assert img8.dtype == np.uint8 and img8.shape == img.shape
+    assert np.array_equal(img8.astype(np.int64), quantise(img))
+    assert host.to_ppm(img8) == host.to_ppm(img)
+    # and against the oracle, to the PPM tolerance
+    ref = quantise(orc.render(mw(orc), mc(orc, W, H)))
+    diff = np.abs(img8.astype(np.int64) - ref)
+    assert diff.max() <= 1 and np.any(diff != 0, axis=2).mean() <= 1e-4
+
+
+def test_clamp_u8_edge_values(host):
+    """Canvas::clamp on the device for colours outside [0, 1], exact multiples of 1/255 and NaN
+    (canvas.rs:50-60, known answers at canvas.rs:172-218): a world that is only an ambient plane
+    whose colour is the value under test."""
+    values = [-0.5, 0.0, 1e-300, 0.5, 1.0, 1.5, 204 / 255, 0.8, float("nan"), float("inf")]
+    for v in values:
+        def world(o, v=v):
+            mat = o.Phong(o.Solid(o.Color(v, v, v)), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0)
+            plane = o.Plane(o.Matrix.translation(0, 0, 5) * o.Matrix.rotation_x(np.pi / 2), mat, True)
+            return o.World([plane], [o.PointLight(o.point(0, 0, -5), o.Color.white())])
+        cam = host.Camera(8, 8, 0.5, host.Matrix.identity())
+        img = host.render(world(host), cam)
+        img8 = host.render_u8(world(host), cam)
+        expect = np.array([[host.clamp(c) for c in px] for px in img.reshape(-1, 3)]).reshape(img.shape)
+        assert np.array_equal(img8.astype(np.int64), expect), v
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_cyclic_tiles_u8_reassemble(host, world_size):
+    W, H = 64, 52
+    mw, mc = scenes.WORKLOADS["default"]
+    full = host.render_u8(mw(host), mc(host, W, H))
+    frame = np.zeros_like(full)
+    for rank in range(world_size):
+        part = host.render_u8(mw(host), mc(host, W, H), rank=rank, world_size=world_size)
+        frame[host.global_rows(H, rank, world_size)] = part
+    assert np.array_equal(frame, full)
