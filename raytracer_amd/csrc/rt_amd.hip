@@ -38,6 +38,7 @@
 #define RT_MAX_FRAMES RT_MAX_DEPTH
 #define RT_PAT_STACK (RT_MAX_PATTERN_NEST + 1)
 #define COUNTER_SHARDS 1024u  // each shard is 16 u64 (one 128-byte line)
+#define COUNTER_WORDS (COUNTER_SHARDS * 16u)
 
 namespace {
 
@@ -788,9 +789,13 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, i
 
 template <bool TRACK, bool XF, bool CULL>
 __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
-                                                 unsigned long long* __restrict__ counters) {
+                                                 unsigned long long* __restrict__ counters,
+                                                 unsigned long long* __restrict__ clear_counters) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
+    // The scene keeps two sets of ray counters; this launch clears the set the next launch will
+    // use, which saves a memset (and its launch gap) per frame.
+    if (clear_counters && blockIdx.x < COUNTER_WORDS / RT_BLOCK) clear_counters[blockIdx.x * RT_BLOCK + threadIdx.x] = 0ull;
     // A lane parks its finished pixel in LDS instead of carrying it through the rest of the
     // wavefront's rounds; the tile is written from there at the end.
     __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
@@ -1212,7 +1217,9 @@ struct rt_scene {
     bool any_xform = false;  // the traversal records include T_XFORM entries
     bool any_cull = false;   // ... and T_CULL entries
     std::vector<void*> allocations;
-    unsigned long long* d_counters = nullptr;
+    unsigned long long* d_counters = nullptr;  // two sets of COUNTER_WORDS, used by alternate launches
+    bool set_clean[2] = {true, true};
+    int next_set = 0, last_set = 0;
     double* d_frame = nullptr;  // staging for the synchronous entry points
     size_t frame_bytes = 0;
     double* d_rays = nullptr;
@@ -1537,19 +1544,29 @@ int local_tile_rows(int height, const rt_params* p) {
 
 int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipStream_t stream) {
     int slot = (int)(s->launches % TIMING_RING);
-    HIP_TRY(hipMemsetAsync(s->d_counters, 0, COUNTER_SHARDS * 16 * sizeof(unsigned long long), stream));
+    // Launches on one scene must be ordered (one stream at a time): each clears the other counter set.
+    const int a = s->next_set, b = a ^ 1;
+    unsigned long long* mine = s->d_counters + (size_t)a * COUNTER_WORDS;
+    unsigned long long* other = s->d_counters + (size_t)b * COUNTER_WORDS;
+    if (!s->set_clean[a]) HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
+    const bool clears_other = blocks >= COUNTER_WORDS / RT_BLOCK;
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (blocks > 0) {
-        using Kernel = void (*)(DevScene, DevJob, double*, unsigned long long*);
+        using Kernel = void (*)(DevScene, DevJob, double*, unsigned long long*, unsigned long long*);
         static const Kernel kernels[8] = {rt_kernel<false, false, false>, rt_kernel<false, false, true>,
                                           rt_kernel<false, true, false>,  rt_kernel<false, true, true>,
                                           rt_kernel<true, false, false>,  rt_kernel<true, false, true>,
                                           rt_kernel<true, true, false>,   rt_kernel<true, true, true>};
         Kernel kernel = kernels[(s->any_transparent ? 4 : 0) | (s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
-        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, s->d_counters);
+        hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, mine,
+                           clears_other ? other : nullptr);
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(s->ev_stop[slot], stream));
+    s->set_clean[a] = blocks == 0;
+    if (clears_other) s->set_clean[b] = true;
+    s->last_set = a;
+    s->next_set = b;
     s->launches++;
     s->last_stream = stream;
     return RT_OK;
@@ -1558,7 +1575,8 @@ int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipSt
 int fill_stats(rt_scene* s, rt_stats* st) {
     if (!st) return RT_OK;
     std::vector<unsigned long long> shards(COUNTER_SHARDS * 16);
-    HIP_TRY(hipMemcpy(shards.data(), s->d_counters, shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(shards.data(), s->d_counters + (size_t)s->last_set * COUNTER_WORDS,
+                      shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long c[16] = {};
     for (unsigned k = 0; k < COUNTER_SHARDS; ++k)
         for (int j = 0; j < 16; ++j) c[j] += shards[k * 16 + j];
@@ -1644,9 +1662,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(d->aabbs[i].min[k]) || !std::isfinite(d->aabbs[i].max[k])) s->dev.finite_bounds = 0;
     void* p = nullptr;
-    if (hipMalloc(&p, COUNTER_SHARDS * 16 * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&p, 2 * COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess)
         return cleanup(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
     s->d_counters = (unsigned long long*)p;
+    if (hipMemset(p, 0, 2 * COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess)
+        return cleanup(fail(RT_ERR_HIP, "hipMemset(counters) failed"));
     for (int i = 0; i < TIMING_RING; ++i) {
         if (hipEventCreate(&s->ev_start[i]) != hipSuccess || hipEventCreate(&s->ev_stop[i]) != hipSuccess)
             return cleanup(fail(RT_ERR_HIP, "hipEventCreate failed"));
