@@ -47,7 +47,7 @@ def cpu_baseline(name, W, H, budget_s=15.0):
     world, cam = mw(orc), mc(orc, W, H)
     threads = 12  # NUM_OF_THREADS, src/lib.rs:23
     band = 2
-    n_bands = 24
+    n_bands = 64
     starts = [int((k + 0.5) * H / n_bands) // band * band for k in range(n_bands)]
     rays = 0
     seconds = 0.0
@@ -75,6 +75,15 @@ def cpu_baseline(name, W, H, budget_s=15.0):
                   "once per hit as on the GPU, timed in the cost-faithful mode" % (rows, len(starts), band, W, H, name, seconds),
         "host_cpus": os.cpu_count(),
     }
+
+
+def load_traffic(workload, W, H):
+    """HBM bytes per launch measured with rocprofv3 PMC passes on this workload (profiles/traffic.json), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    entry = json.load(open(path)).get("%s_%dx%d" % (workload, W, H))
+    return entry["bytes_per_launch"] if entry else None
 
 
 def main():
@@ -215,7 +224,7 @@ def main():
                 "peak": FP64_VECTOR_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                "traffic": None,
+                "traffic": load_traffic(args.workload, W, H) if world_size == 1 else None,
                 "peak_without_fma": FP64_VECTOR_PEAK_TFLOPS / 2,
                 "frac_without_fma": achieved / (FP64_VECTOR_PEAK_TFLOPS / 2),
                 "algorithmic_flops_per_launch": flops / world_size,

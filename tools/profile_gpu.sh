@@ -9,7 +9,7 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export PYTHONPATH=$ROOT TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 50 --warmup 3 --no-cpu-baseline $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
 PMC_BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
 i=0
