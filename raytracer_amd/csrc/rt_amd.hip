@@ -247,6 +247,15 @@ DI double rcp_exact(double d) {
 DI double reciprocal1(double d) { return fabs(d) >= RT_EPS ? rcp_exact(d) : __builtin_nan(""); }
 DI V3 reciprocal(V3 d) { return mk(reciprocal1(d.x), reciprocal1(d.y), reciprocal1(d.z)); }
 
+// Slack, in ray-time units, for pruning subtrees by their box times: a child's computed time can
+// differ from the box times of its group by rounding, which grows with the square of the origin's
+// distance (cancellation in the quadratics) and with 1/|direction| (time per unit length).
+DI double prune_margin(double origin_sq, V3 rcp_dir) {
+    double r = fmax(fmax(fabs(rcp_dir.x), fabs(rcp_dir.y)), fabs(rcp_dir.z));  // NaN components are ignored
+    double m = (1e-9 * (1.0 + origin_sq)) * r;
+    return (m == m) ? m : INFINITY;  // no finite reciprocal at all: never prune
+}
+
 // Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
 // for the n1/n2 bookkeeping, the parity and the latest of the leaf's non-positive times.
 struct LeafAcc {
@@ -272,7 +281,6 @@ struct Hit {
     bool found;
     double t;
     int node;
-    double u, v;
     // World::prepare_computations container walk (world.rs:99-132), reduced to what decides
     // n1/n2: whether the hit leaf has an odd number of earlier intersections, and the two
     // leaves with an odd count whose last earlier intersection comes latest in sorted order.
@@ -309,8 +317,6 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     h.found = false;
     h.t = 0.0;
     h.node = -1;
-    h.u = 0.0;
-    h.v = 0.0;
     h.par = 0;
     h.a_t = 0.0;
     h.b_t = 0.0;
@@ -327,7 +333,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     int cur_ctx = -1;
     V3 co = wo, cd = wd;  // the ray in the space of the transformed group `cur_ctx`
     V3 cy = reciprocal(cd);  // exact reciprocals of cd, used by the fast slab test
-    double coo = CULL ? dot(co, co) : 0.0;  // scales the padding of T_CULL boxes
+    double coo = dot(co, co);   // scales the padding of T_CULL boxes
+    double tpad = prune_margin(coo, cy);
     bool cfin = all_axes_finite(cd);
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
 
@@ -360,7 +367,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             cd = wd;
             chain_ray(S, ctx, co, cd);
             cy = reciprocal(cd);
-            if (CULL) coo = dot(co, co);
+            coo = dot(co, co);
+            tpad = prune_margin(coo, cy);
             cfin = all_axes_finite(cd);
             cur_ctx = ctx;
         }
@@ -372,7 +380,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             co = to;
             cd = td;
             cy = reciprocal(cd);
-            if (CULL) coo = dot(co, co);
+            coo = dot(co, co);
+            tpad = prune_margin(coo, cy);
             cfin = all_axes_finite(cd);
             cur_ctx = i;
             i = i + 1;
@@ -407,6 +416,13 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             else
                 slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
             bool inside = act && !(tmin > tmax);
+            // The reference enters every group whose box the ray's LINE meets.  Subtrees that can
+            // only yield times that do not count are skipped: behind the origin (unless the n1/n2
+            // bookkeeping needs the times <= 0), beyond the light, beyond the nearest hit so far.
+            // tpad absorbs the rounding between a child's time and its group's box times.
+            if (!TRACK) inside = inside && !(tmax < -tpad);
+            if (MODE == MODE_SHADOW) inside = inside && !(tmin > limit + tpad);
+            inside = inside && !(h.found && tmin > h.t + tpad);
             if (act && !inside) skip_until = skip;
             i = (__ballot(inside) == 0ull) ? skip : i + 1;
             continue;
@@ -422,7 +438,6 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         acc.found = false;
         acc.par = 0;
         acc.negmax = -INFINITY;
-        double hu = 0.0, hv = 0.0;
         if (act) {
             switch (type) {
                 case RT_SPHERE: {  // sphere.rs:52-78
@@ -527,9 +542,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                             double v = f * dot(ld, origin_cross_e1);
                             if (!(v < 0.0 || (u + v) > 1.0)) {
                                 double t = f * dot(e2, origin_cross_e1);
-                                leaf_add<TRACK>(acc, t);
-                                hu = u;
-                                hv = v;
+                                leaf_add<TRACK>(acc, t);  // u and v are recomputed when the hit is shaded
                             }
                         }
                     }
@@ -542,8 +555,6 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 h.found = true;
                 h.t = acc.best;
                 h.node = rnode;
-                h.u = hu;
-                h.v = hv;
                 h.par = acc.par;
             }
             if (TRACK && acc.par) {
@@ -910,10 +921,32 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
                     ln = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
                     break;
                 default: {  // smooth_triangle.rs:160-162
+                    // The hit's u and v (smooth_triangle.rs:101-129) are not carried through the
+                    // traversal: the same operations on the same ray give the same bits here.
+                    V3 lo = ro, ld = rd;
+#pragma unroll
+                    for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
+                        if (sr->anc_xf[k] >= 0) {
+                            const RT_CONST double* m = S.xforms[sr->anc_xf[k]].inv;
+                            lo = xpoint(m, lo);
+                            ld = xvec(m, ld);
+                        }
+                    if (sflags & S_HAS_XFORM) {
+                        lo = xpoint(sr->inv, lo);
+                        ld = xvec(sr->inv, ld);
+                    }
+                    V3 tp1 = mk(S.tris[data].p1[0], S.tris[data].p1[1], S.tris[data].p1[2]);
+                    V3 te1 = mk(S.tris[data].e1[0], S.tris[data].e1[1], S.tris[data].e1[2]);
+                    V3 te2 = mk(S.tris[data].e2[0], S.tris[data].e2[1], S.tris[data].e2[2]);
+                    V3 dir_cross_e2 = cross(ld, te2);
+                    double tf = 1.0 / dot(te1, dir_cross_e2);
+                    V3 p1_to_origin = lo - tp1;
+                    double hit_u = tf * dot(p1_to_origin, dir_cross_e2);
+                    double hit_v = tf * dot(ld, cross(p1_to_origin, te1));
                     V3 a1 = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
                     V3 a2 = mk(S.trin[data].n2[0], S.trin[data].n2[1], S.trin[data].n2[2]);
                     V3 a3 = mk(S.trin[data].n3[0], S.trin[data].n3[1], S.trin[data].n3[2]);
-                    ln = (a2 * h.u) + (a3 * h.v) + (a1 * (1.0 - h.u - h.v));
+                    ln = (a2 * hit_u) + (a3 * hit_v) + (a1 * (1.0 - hit_u - hit_v));
                     break;
                 }
             }
