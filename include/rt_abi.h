@@ -36,25 +36,33 @@ typedef enum rt_status {
 #define RT_MAX_XFORM_NEST 4    /* nested groups with a non-identity transform */
 #define RT_MAX_PATTERN_NEST 4  /* nested gradient/blended patterns */
 #define RT_TILE 8              /* a wavefront renders an 8x8 pixel tile */
+#define RT_MAX_CSG_NEST 4      /* CSG shapes nested inside one another */
+#define RT_MAX_CSG_HITS 24     /* most intersections one ray can have with an outermost CSG shape:
+                                  sphere, cube 2 each; cylinder, cone 4; plane, triangles 1 */
 
 /* Node kinds: the shapes of src/geometry/{group,sphere,plane,cube,cylinder,cone,triangle,
- * smooth_triangle}.rs. */
-enum { RT_GROUP = 0, RT_SPHERE, RT_PLANE, RT_CUBE, RT_CYLINDER, RT_CONE, RT_TRIANGLE, RT_SMOOTH_TRIANGLE };
-enum { RT_NODE_CASTS_SHADOW = 1, RT_NODE_CLOSED = 2 };
+ * smooth_triangle,csg}.rs.  An RT_CSG node has exactly two children: its left operand is the next
+ * node, its right operand starts where the left one's subtree ends (src/geometry/csg.rs:15-25). */
+enum { RT_GROUP = 0, RT_SPHERE, RT_PLANE, RT_CUBE, RT_CYLINDER, RT_CONE, RT_TRIANGLE, RT_SMOOTH_TRIANGLE, RT_CSG };
+enum { RT_NODE_CASTS_SHADOW = 1, RT_NODE_CLOSED = 2,
+       /* RT_CSG: the Operation (src/geometry/csg.rs:27-31) in bits 4-5 */
+       RT_NODE_CSG_DIFFERENCE = 0 << 4, RT_NODE_CSG_INTERSECTION = 1 << 4, RT_NODE_CSG_UNION = 2 << 4,
+       RT_NODE_CSG_OP_MASK = 3 << 4 };
 
 /* One scene-graph node.  Nodes are stored in depth-first pre-order, children in the order the
  * reference keeps them in Group::children (src/geometry/group.rs:19), top-level objects in
  * World::objects order (src/scene/world.rs:16).  That order is what breaks ties between equal
  * intersection times, because the reference's sorts are stable. */
 typedef struct rt_node {
-    int32_t type;     /* RT_GROUP ... RT_SMOOTH_TRIANGLE */
+    int32_t type;     /* RT_GROUP ... RT_CSG */
     int32_t flags;    /* RT_NODE_* */
     int32_t parent;   /* enclosing group, -1 for a World object */
     int32_t skip;     /* first node after this node's subtree (== index + 1 for a leaf) */
-    int32_t material; /* leaves: index into materials; groups: -1 */
+    int32_t material; /* leaves: index into materials; groups and CSG shapes: -1 (a CSG shape's own
+                         material is never used: intersections carry the operand that was hit) */
     int32_t xform;    /* index into xforms, or -1 when the node's transform is the identity */
-    int32_t data;     /* group: aabbs index; cylinder/cone: ranges index; triangles: tris index; else -1 */
-    int32_t ctx;      /* nearest enclosing group whose transform is not the identity, or -1 */
+    int32_t data;     /* group, CSG: aabbs index; cylinder/cone: ranges index; triangles: tris index; else -1 */
+    int32_t ctx;      /* nearest enclosing group or CSG shape whose transform is not the identity, or -1 */
 } rt_node;
 
 /* Inverse of a node transform, computed on the host by the reference's cofactor algorithm

@@ -580,7 +580,8 @@ struct Material {
 // ---------------------------------------------------------------------------------------------
 // Shapes (geometry/*.rs)
 // ---------------------------------------------------------------------------------------------
-enum ShapeKind { S_GROUP = 0, S_SPHERE, S_PLANE, S_CUBE, S_CYLINDER, S_CONE, S_TRIANGLE, S_SMOOTH };
+enum ShapeKind { S_GROUP = 0, S_SPHERE, S_PLANE, S_CUBE, S_CYLINDER, S_CONE, S_TRIANGLE, S_SMOOTH, S_CSG };
+enum CsgOp { CSG_DIFFERENCE = 0, CSG_INTERSECTION = 1, CSG_UNION = 2 };  // csg.rs:27-31
 
 struct Hit {
     double t;
@@ -607,7 +608,8 @@ struct Shape {
     bool closed = false;
     // triangles
     Tuple p1{}, p2{}, p3{}, e1{}, e2{}, normal{}, n1{}, n2{}, n3{};
-    // group
+    // group; a CSG shape keeps its left and right operands as children[0] and children[1]
+    int op = CSG_UNION;
     std::vector<std::shared_ptr<Shape>> children;
     bool bounds_valid = false;
     BBox cached_bounds{};
@@ -634,6 +636,18 @@ struct Shape {
                         std::stable_sort(out.begin() + first, out.end(), [](const Hit& a, const Hit& b) {
                             return total_key(a.t) < total_key(b.t);
                         });
+                }
+                return;
+            }
+            case S_CSG: {  // csg.rs:144-159
+                if (bbox_intersects(const_cast<Shape*>(this)->bounds(), r)) {
+                    size_t first = out.size();
+                    children[0]->intersect(r, out);
+                    children[1]->intersect(r, out);
+                    std::stable_sort(out.begin() + first, out.end(), [](const Hit& a, const Hit& b) {
+                        return total_key(a.t) < total_key(b.t);
+                    });
+                    filter_intersections(out, first);
                 }
                 return;
             }
@@ -803,9 +817,44 @@ struct Shape {
             case S_SMOOTH:  // smooth_triangle.rs:160-162
                 return (n2 * hit.u) + (n3 * hit.v) + (n1 * (1.0 - hit.u - hit.v));
             case S_GROUP:
+            case S_CSG:  // csg.rs:181-183 panics; intersections never carry a CSG shape as their object
                 break;
         }
         return vec(0, 0, 0);
+    }
+
+    // Shape::includes: leaves compare identity, groups and CSG shapes ask their children
+    // (group.rs:172-182, csg.rs:177-179).
+    bool includes(const Shape* other) const {
+        if (kind != S_GROUP && kind != S_CSG) return this == other;
+        for (auto& c : children)
+            if (c->includes(other)) return true;
+        return false;
+    }
+    // csg.rs:113-140
+    static bool intersection_allowed(int op, bool lhit, bool inl, bool inr) {
+        switch (op) {
+            case CSG_DIFFERENCE:
+                return (lhit && !inr) || (!lhit && inl);
+            case CSG_INTERSECTION:
+                return (lhit && inr) || (!lhit && inl);
+            default:
+                return (lhit && !inr) || (!lhit && !inl);
+        }
+    }
+    // csg.rs:80-107, on the tail of `xs` that starts at `first`
+    void filter_intersections(std::vector<Hit>& xs, size_t first) const {
+        bool inl = false, inr = false;
+        size_t keep = first;
+        for (size_t i = first; i < xs.size(); ++i) {
+            bool lhit = children[0]->includes(xs[i].obj);
+            if (intersection_allowed(op, lhit, inl, inr)) xs[keep++] = xs[i];
+            if (lhit)
+                inl = !inl;
+            else
+                inr = !inr;
+        }
+        xs.resize(keep);
     }
 
     // shape.rs:65-79
@@ -844,6 +893,7 @@ struct Shape {
             case S_TRIANGLE:
             case S_SMOOTH:  // triangle.rs:146-153
                 return bbox_add_point(bbox_add_point(bbox_add_point(bbox_empty(), p1), p2), p3);
+            case S_CSG:      // csg.rs:74-78, 185-202: the same fold over the two operands
             case S_GROUP: {  // group.rs:196-208, 66-77
                 if (!bounds_valid) {
                     BBox r = bbox_empty();
@@ -866,6 +916,11 @@ struct Shape {
     }
     // group.rs:224-244, 79-115
     void divide(size_t threshold) {
+        if (kind == S_CSG) {  // csg.rs:216-219
+            children[0]->divide(threshold);
+            children[1]->divide(threshold);
+            return;
+        }
         if (kind != S_GROUP) return;
         if (threshold <= children.size()) {
             BBox lb, rb;
@@ -1491,6 +1546,32 @@ int64_t orc_group(const double* m) {
     s->xf = Xform(from_rows(m));
     return g_reg.add_shape(s);
 }
+// CSG::new (csg.rs:34-59): casts_shadow is false, both operands get the new shape as parent.
+int64_t orc_csg(int op, int64_t left, int64_t right, const double* m, int64_t material) {
+    auto s = std::make_shared<Shape>();
+    s->kind = S_CSG;
+    s->op = op;
+    s->xf = Xform(from_rows(m));
+    s->material = g_reg.materials.at(material);
+    s->casts_shadow = false;
+    s->add_child(g_reg.shapes.at(left));
+    s->add_child(g_reg.shapes.at(right));
+    return g_reg.add_shape(s);
+}
+int orc_csg_allowed(int op, int lhit, int inl, int inr) {
+    return Shape::intersection_allowed(op, lhit != 0, inl != 0, inr != 0) ? 1 : 0;
+}
+// CSG::filter_intersections on a caller-supplied list; returns how many survive, keeps them in place.
+int orc_csg_filter(int64_t h, int n, double* ts, int64_t* objs) {
+    std::vector<Hit> xs;
+    for (int i = 0; i < n; ++i) xs.push_back({ts[i], g_reg.shapes.at(objs[i]).get(), 0, 0});
+    g_reg.shapes.at(h)->filter_intersections(xs, 0);
+    for (size_t i = 0; i < xs.size(); ++i) {
+        ts[i] = xs[i].t;
+        objs[i] = g_reg.shape_ids.at(xs[i].obj);
+    }
+    return (int)xs.size();
+}
 int orc_group_add_child(int64_t g, int64_t c) {
     auto& grp = g_reg.shapes.at(g);
     if (grp->kind != S_GROUP) return -1;
@@ -1742,7 +1823,7 @@ int orc_is_shadowed(int64_t w, const double* p, const double* lpos, const double
 // rgb (full-frame layout, (y*W + x)*3).  Work is split over `threads` workers striding the linear
 // pixel index like lib.rs:94-111.  counters (16 x u64) may be NULL.
 static void warm_bounds(Shape* s) {
-    if (s->kind != S_GROUP) return;
+    if (s->kind != S_GROUP && s->kind != S_CSG) return;
     s->bounds();
     for (auto& c : s->children) warm_bounds(c.get());
 }

@@ -242,9 +242,23 @@ struct Shape {
     double minimum = -INF, maximum = INF;
     bool closed = false;
     Tuple p1{}, p2{}, p3{}, e1{}, e2{}, normal{}, n1{}, n2{}, n3{};
-    std::vector<std::shared_ptr<Shape>> children;
+    std::vector<std::shared_ptr<Shape>> children;  // RT_CSG: left and right operand
+    int op = 2;                                     // RT_CSG: 0 difference, 1 intersection, 2 union (csg.rs:27-31)
     bool bounds_valid = false;
     BoundingBox cached{};
+
+    // Shape::includes (group.rs:172-182, csg.rs:177-179; leaves compare identity)
+    bool includes(const Shape* other) const {
+        if (kind != RT_GROUP && kind != RT_CSG) return this == other;
+        for (auto& c : children)
+            if (c->includes(other)) return true;
+        return false;
+    }
+    static bool intersection_allowed(int op, bool lhit, bool inl, bool inr) {  // csg.rs:113-140
+        if (op == 0) return (lhit && !inr) || (!lhit && inl);
+        if (op == 1) return (lhit && inr) || (!lhit && inl);
+        return (lhit && !inr) || (!lhit && !inl);
+    }
 
     BoundingBox bounds() {
         switch (kind) {
@@ -262,7 +276,7 @@ struct Shape {
             case RT_TRIANGLE:
             case RT_SMOOTH_TRIANGLE:  // triangle.rs:146-153
                 return BoundingBox::empty().add_point(p1).add_point(p2).add_point(p3);
-            default:  // group.rs:196-208, 66-77
+            default:  // group.rs:196-208, 66-77; csg.rs:74-78 folds its two operands the same way
                 if (!bounds_valid) {
                     BoundingBox r = BoundingBox::empty();
                     for (auto& c : children) r = r.merged(c->parent_space_bounds_of());
@@ -285,6 +299,11 @@ struct Shape {
         add_child(g);
     }
     void divide(size_t threshold) {  // group.rs:224-244, 79-105
+        if (kind == RT_CSG) {        // csg.rs:216-219
+            children[0]->divide(threshold);
+            children[1]->divide(threshold);
+            return;
+        }
         if (kind != RT_GROUP) return;
         if (threshold <= children.size()) {
             BoundingBox lb, rb;
@@ -580,7 +599,8 @@ struct Flattener {
             n.xform = (int)f.xforms.size();
             f.xforms.push_back(x);
         }
-        if (s->kind == RT_GROUP) {
+        if (s->kind == RT_CSG) n.flags = (s->casts_shadow ? RT_NODE_CASTS_SHADOW : 0) | (s->op << 4);
+        if (s->kind == RT_GROUP || s->kind == RT_CSG) {
             BoundingBox b = s->bounds();
             rt_aabb a{{b.min.x, b.min.y, b.min.z}, {b.max.x, b.max.y, b.max.z}};
             n.data = (int)f.aabbs.size();
@@ -871,6 +891,41 @@ int64_t rth_group(const double* m) {
     auto s = std::make_shared<Shape>();
     s->transform = Matrix::rows(m);
     return g_reg.add(s);
+}
+// CSG::new (csg.rs:34-59): casts_shadow is false, both operands get the new shape as parent.
+int64_t rth_csg(int op, int64_t left, int64_t right, const double* m, int64_t material) {
+    auto s = std::make_shared<Shape>();
+    s->kind = RT_CSG;
+    s->op = op;
+    s->transform = Matrix::rows(m);
+    s->material = g_reg.materials.at(material);
+    s->casts_shadow = false;
+    s->add_child(g_reg.shapes.at(left));
+    s->add_child(g_reg.shapes.at(right));
+    invalidate_worlds();
+    return g_reg.add(s);
+}
+int rth_csg_allowed(int op, int lhit, int inl, int inr) {
+    return Shape::intersection_allowed(op, lhit != 0, inl != 0, inr != 0) ? 1 : 0;
+}
+// CSG::filter_intersections (csg.rs:80-107) on a caller-supplied list, survivors kept in place.
+int rth_csg_filter(int64_t h, int n, double* ts, int64_t* objs) {
+    auto& csg = g_reg.shapes.at(h);
+    bool inl = false, inr = false;
+    int keep = 0;
+    for (int i = 0; i < n; ++i) {
+        bool lhit = csg->children.at(0)->includes(g_reg.shapes.at(objs[i]).get());
+        if (Shape::intersection_allowed(csg->op, lhit, inl, inr)) {
+            ts[keep] = ts[i];
+            objs[keep] = objs[i];
+            ++keep;
+        }
+        if (lhit)
+            inl = !inl;
+        else
+            inr = !inr;
+    }
+    return keep;
 }
 int rth_group_add_child(int64_t g, int64_t c) {
     auto& grp = g_reg.shapes.at(g);

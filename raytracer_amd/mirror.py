@@ -78,7 +78,8 @@ class PointLight:
 
 
 # Shape / pattern kind codes shared by every native library behind this module.
-GROUP, SPHERE, PLANE, CUBE, CYLINDER, CONE, TRIANGLE, SMOOTH_TRIANGLE = range(8)
+GROUP, SPHERE, PLANE, CUBE, CYLINDER, CONE, TRIANGLE, SMOOTH_TRIANGLE, CSG_SHAPE = range(9)
+DIFFERENCE, INTERSECTION, UNION = range(3)  # Operation (src/geometry/csg.rs:27-31)
 P_SOLID, P_STRIPED, P_GRADIENT, P_RING, P_CHECKER, P_BLENDED, P_PERTURBED, P_TEST = range(8)
 
 
@@ -245,7 +246,23 @@ class Api:
                 api._f("divide")(self.h, int(threshold))
 
             def num_of_children(self):
-                return api._f("group_num_children")(self.h) if self.kind == GROUP else 0
+                return api._f("group_num_children")(self.h) if self.kind in (GROUP, CSG_SHAPE) else 0
+
+            def left(self):
+                """CSG::left (src/geometry/csg.rs:66-68)."""
+                return self.get_child(0)
+
+            def right(self):
+                """CSG::right (src/geometry/csg.rs:70-72)."""
+                return self.get_child(1)
+
+            def filter_intersections(self, intersections):
+                """CSG::filter_intersections (src/geometry/csg.rs:80-107) on [(t, shape), ...]."""
+                n = len(intersections)
+                ts = (c_d * max(n, 1))(*[float(t) for t, _ in intersections])
+                objs = (c_i64 * max(n, 1))(*[o.h for _, o in intersections])
+                k = api._f("csg_filter")(self.h, n, ts, objs)
+                return [(ts[i], objs[i]) for i in range(k)]
 
             def get_child(self, i):
                 h = api._f("group_child")(self.h, int(i))
@@ -309,6 +326,17 @@ class Api:
             """Group::new / Group::default (src/geometry/group.rs:26-48)."""
             transform = transform or Matrix.identity()
             return Shape(api._f("group")(_arr(transform.v)), GROUP, transform, None, True)
+
+        def CSG(operation, left, right, transform=None, material=None):
+            """CSG::new / CSG::default (src/geometry/csg.rs:34-64); casts_shadow is false there."""
+            transform = transform or Matrix.identity()
+            material = material or Phong.default()
+            h = api._f("csg")(int(operation), left.h, right.h, _arr(transform.v), material.h)
+            return Shape(h, CSG_SHAPE, transform, material, False)
+
+        def intersection_allowed(operation, lhit, inl, inr):
+            """CSG::intersection_allowed (src/geometry/csg.rs:113-140)."""
+            return bool(api._f("csg_allowed")(int(operation), int(lhit), int(inl), int(inr)))
 
         class ObjFileParser:
             """ObjFileParser (src/scene/obj_file_parser.rs:23-235)."""
@@ -409,6 +437,9 @@ class Api:
         self.Triangle = Triangle
         self.SmoothTriangle = SmoothTriangle
         self.Group = Group
+        self.CSG = CSG
+        self.intersection_allowed = intersection_allowed
+        self.DIFFERENCE, self.INTERSECTION, self.UNION = DIFFERENCE, INTERSECTION, UNION
         self.ObjFileParser = ObjFileParser
         self.World = World
         self.Camera = Camera
@@ -456,6 +487,9 @@ class Api:
             "smooth_triangle": (c_i64, [c_dp, c_dp, c_dp, c_i64, C.c_int]),
             "group": (c_i64, [c_dp]),
             "group_add_child": (C.c_int, [c_i64, c_i64]),
+            "csg": (c_i64, [C.c_int, c_i64, c_i64, c_dp, c_i64]),
+            "csg_allowed": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int]),
+            "csg_filter": (C.c_int, [c_i64, C.c_int, c_dp, C.POINTER(c_i64)]),
             "shape_kind": (C.c_int, [c_i64]),
             "group_num_children": (C.c_int, [c_i64]),
             "group_child": (c_i64, [c_i64, C.c_int]),
