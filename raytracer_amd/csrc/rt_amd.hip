@@ -49,7 +49,12 @@ namespace {
 // A finite sphere, cube or cylinder leaf is preceded by a T_CULL record: a padded box
 // around the leaf in the space its ray arrives in.  Lanes whose ray cannot reach the box skip
 // the leaf; this never changes a result, it only avoids arithmetic whose outcome is "no hit".
-enum { T_XFORM = 8, T_CULL = 9, T_HAS_INV = 0x100, T_CLOSED = 0x200, T_OWN_XFORM = 0x400 };
+// A CSG shape (csg.rs) is bracketed by T_CSG_BEGIN (its box; `node` = index of the matching end
+// record) and T_CSG_END (`node` = the CSG node, `skip` = first node after its left operand, the
+// operation in bits 12-13).  Between them the leaves collect their intersections per lane instead
+// of competing for the nearest hit; the end record sorts and filters them.
+enum { T_XFORM = 8, T_CULL = 9, T_CSG_BEGIN = 10, T_CSG_END = 11, T_HAS_INV = 0x100, T_CLOSED = 0x200,
+       T_OWN_XFORM = 0x400, T_CSG_OP_SHIFT = 12 };
 struct alignas(16) TRec {
     int kind;    // low byte: RT_* type or T_XFORM; T_HAS_INV: p holds rows 0..2 of the inverse; T_CLOSED;
                  // T_OWN_XFORM: the record before this one is this node's T_XFORM record
@@ -264,8 +269,21 @@ struct LeafAcc {
     int par;
     double negmax;
 };
+// Per-lane list of the intersections collected inside the outermost CSG shape being traversed.
+struct CsgList {
+    double t[RT_MAX_CSG_HITS];
+    int id[RT_MAX_CSG_HITS];
+    int n;
+    int start[RT_MAX_CSG_NEST];  // list length when each open CSG shape began
+};
+// f64::total_cmp as an integer key (intersection.rs:60-64).
+DI long long total_key(double v) {
+    long long b = __double_as_longlong(v);
+    b ^= (long long)((unsigned long long)(b >> 63) >> 1);
+    return b;
+}
 template <bool TRACK>
-DI void leaf_add(LeafAcc& a, double t) {
+DI void leaf_count(LeafAcc& a, double t) {
     if (t > 0.0) {
         if (!a.found || t < a.best) {
             a.best = t;
@@ -310,8 +328,8 @@ enum { MODE_CLOSEST = 0, MODE_CLOSEST_TRACK = 1, MODE_SHADOW = 2 };
 // at its first intersection in (0, limit) (any such intersection implies the nearest one is too).
 // XF: the scene has transformed groups or triangles (T_XFORM records); without them the ray never
 // changes space between records and the world-space copy is not kept.
-// CULL: the scene has T_CULL records.
-template <int MODE, bool XF, bool CULL>
+// CULL: the scene has T_CULL records.  CSGM: it has CSG shapes.
+template <int MODE, bool XF, bool CULL, bool CSGM>
 DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
     constexpr bool TRACK = MODE == MODE_CLOSEST_TRACK;
     h.found = false;
@@ -337,6 +355,52 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     double tpad = prune_margin(coo, cy);
     bool cfin = all_axes_finite(cd);
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
+    int csg_depth = 0;  // open CSG shapes around the current record (wave-uniform)
+    CsgList cl;
+    cl.n = 0;
+    LeafAcc acc;
+    int acc_node = -1;
+    // Intersection::hit and the container walk, one leaf at a time in depth-first order.  Stable
+    // sorts keep that order among equal times, so a later leaf only wins with a strictly smaller
+    // time (group.rs:147, world.rs:65).
+    auto begin_leaf = [&](int node) {
+        acc.best = 0.0;
+        acc.found = false;
+        acc.par = 0;
+        acc.negmax = -INFINITY;
+        acc_node = node;
+    };
+    auto leaf_add = [&](double t) {
+        if (CSGM && csg_depth > 0) {
+            if (cl.n < RT_MAX_CSG_HITS) {
+                cl.t[cl.n] = t;
+                cl.id[cl.n] = acc_node;
+            }
+            ++cl.n;
+        } else {
+            leaf_count<TRACK>(acc, t);
+        }
+    };
+    auto commit_leaf = [&]() {
+        if (acc.found && (!h.found || acc.best < h.t)) {
+            h.found = true;
+            h.t = acc.best;
+            h.node = acc_node;
+            h.par = acc.par;
+        }
+        if (TRACK && acc.par) {
+            if (h.a_id < 0 || acc.negmax >= h.a_t) {
+                h.b_t = h.a_t;
+                h.b_id = h.a_id;
+                h.a_t = acc.negmax;
+                h.a_id = acc_node;
+            } else if (h.b_id < 0 || acc.negmax >= h.b_t) {
+                h.b_t = acc.negmax;
+                h.b_id = acc_node;
+            }
+        }
+        if (early && h.found && h.t < limit) skip_until = INT_MAX;  // this lane is decided
+    };
 
 #ifdef RT_PROFILE
     h.visits = 0;
@@ -400,16 +464,82 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             double tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
             double tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
             bool keep = !(tmin > tmax);
-            if (!TRACK) keep = keep && !(tmax < 0.0);                     // only positive times count
-            if (MODE == MODE_SHADOW) keep = keep && !(tmin > limit);     // beyond the light
-            keep = keep && !(h.found && tmin > h.t);                     // behind the nearest hit so far
+            if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
+                if (!TRACK) keep = keep && !(tmax < 0.0);                     // only positive times count
+                if (MODE == MODE_SHADOW) keep = keep && !(tmin > limit);     // beyond the light
+                keep = keep && !(h.found && tmin > h.t);                     // behind the nearest hit so far
+            }
             keep = keep && act;
             if (act && !keep) skip_until = skip;
             i = (__ballot(keep) == 0ull) ? skip : i + 1;
             continue;
         }
-        if (type == RT_GROUP) {
-            // Group::local_intersect (group.rs:133-154): bounds test in the group's own space.
+        if (CSGM && type == T_CSG_END) {
+            // CSG::local_intersect after its operands (csg.rs:150-155): sort this shape's part of
+            // the list by time (stable, total order) and keep what filter_intersections keeps.
+            --csg_depth;
+            const int first = cl.start[csg_depth];
+            const int last = cl.n < RT_MAX_CSG_HITS ? cl.n : RT_MAX_CSG_HITS;
+            for (int a = first + 1; a < last; ++a) {
+                const double ta = cl.t[a];
+                const int ia = cl.id[a];
+                const long long ka = total_key(ta);
+                int b = a - 1;
+                while (b >= first && total_key(cl.t[b]) > ka) {
+                    cl.t[b + 1] = cl.t[b];
+                    cl.id[b + 1] = cl.id[b];
+                    --b;
+                }
+                cl.t[b + 1] = ta;
+                cl.id[b + 1] = ia;
+            }
+            const int op = (kind >> T_CSG_OP_SHIFT) & 3;
+            bool inl = false, inr = false;
+            int kept = first;
+            for (int a = first; a < last; ++a) {
+                const bool lhit = cl.id[a] > rnode && cl.id[a] < skip;  // the left operand's nodes (csg.rs:91)
+                bool allowed;                                           // csg.rs:113-140
+                if (op == 0)
+                    allowed = (lhit && !inr) || (!lhit && inl);
+                else if (op == 1)
+                    allowed = (lhit && inr) || (!lhit && inl);
+                else
+                    allowed = (lhit && !inr) || (!lhit && !inl);
+                if (allowed) {
+                    cl.t[kept] = cl.t[a];
+                    cl.id[kept] = cl.id[a];
+                    ++kept;
+                }
+                if (lhit)
+                    inl = !inl;
+                else
+                    inr = !inr;
+            }
+            cl.n = kept;
+            if (csg_depth == 0) {
+                // The survivors join the enclosing list: hand them over leaf by leaf in depth-first
+                // (= node) order, exactly as if each leaf had produced only these intersections.
+                int done = -1;
+                for (;;) {
+                    int next = INT_MAX;
+                    for (int a = 0; a < cl.n; ++a)
+                        if (cl.id[a] > done && cl.id[a] < next) next = cl.id[a];
+                    if (next == INT_MAX) break;
+                    begin_leaf(next);
+                    for (int a = 0; a < cl.n; ++a)
+                        if (cl.id[a] == next) leaf_count<TRACK>(acc, cl.t[a]);
+                    commit_leaf();
+                    done = next;
+                }
+                cl.n = 0;
+            }
+            i = i + 1;
+            if (early && __ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
+            continue;
+        }
+        if (type == RT_GROUP || (CSGM && type == T_CSG_BEGIN)) {
+            // Group::local_intersect (group.rs:133-154) and CSG::local_intersect (csg.rs:145):
+            // bounds test in the shape's own space.
             double tmin, tmax;
             if (S.finite_bounds && __ballot(act && !cfin) == 0ull)
                 slabs_fast(co, cd, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
@@ -420,11 +550,18 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // only yield times that do not count are skipped: behind the origin (unless the n1/n2
             // bookkeeping needs the times <= 0), beyond the light, beyond the nearest hit so far.
             // tpad absorbs the rounding between a child's time and its group's box times.
-            if (!TRACK) inside = inside && !(tmax < -tpad);
-            if (MODE == MODE_SHADOW) inside = inside && !(tmin > limit + tpad);
-            inside = inside && !(h.found && tmin > h.t + tpad);
+            if (!CSGM || csg_depth == 0) {  // inside a CSG shape its filter needs every intersection
+                if (!TRACK) inside = inside && !(tmax < -tpad);
+                if (MODE == MODE_SHADOW) inside = inside && !(tmin > limit + tpad);
+                inside = inside && !(h.found && tmin > h.t + tpad);
+            }
             if (act && !inside) skip_until = skip;
-            i = (__ballot(inside) == 0ull) ? skip : i + 1;
+            const bool enter = __ballot(inside) != 0ull;
+            if (CSGM && type == T_CSG_BEGIN && enter) {
+                cl.start[csg_depth] = cl.n;
+                ++csg_depth;
+            }
+            i = enter ? i + 1 : skip;
             continue;
         }
         V3 lo = co, ld = cd;
@@ -433,11 +570,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             ld = xvec(q, cd);
         }
 
-        LeafAcc acc;
-        acc.best = 0.0;
-        acc.found = false;
-        acc.par = 0;
-        acc.negmax = -INFINITY;
+        begin_leaf(rnode);
         if (act) {
             switch (type) {
                 case RT_SPHERE: {  // sphere.rs:52-78
@@ -448,13 +581,13 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     if (!(disc < 0.0)) {
                         double sq = sqrt(disc);
                         double den = a * 2.0;
-                        leaf_add<TRACK>(acc, (-b + sq) / den);
-                        leaf_add<TRACK>(acc, (-b - sq) / den);
+                        leaf_add((-b + sq) / den);
+                        leaf_add((-b - sq) / den);
                     }
                     break;
                 }
                 case RT_PLANE: {  // plane.rs:51-74
-                    if (!(fabs(ld.y) < RT_EPS)) leaf_add<TRACK>(acc, -lo.y / ld.y);
+                    if (!(fabs(ld.y) < RT_EPS)) leaf_add(-lo.y / ld.y);
                     break;
                 }
                 case RT_CUBE: {  // cube.rs:77-98
@@ -464,8 +597,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     else
                         slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
                     if (!(tmin > tmax)) {
-                        leaf_add<TRACK>(acc, tmin);
-                        leaf_add<TRACK>(acc, tmax);
+                        leaf_add(tmin);
+                        leaf_add(tmax);
                     }
                     break;
                 }
@@ -486,7 +619,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                             if (fabs(b) < RT_EPS) {
                                 done = true;  // misses walls and caps (cone.rs:119-121)
                             } else {
-                                leaf_add<TRACK>(acc, -c / (2.0 * b));
+                                leaf_add(-c / (2.0 * b));
                             }
                         }
                     } else {
@@ -508,9 +641,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                                     t1 = tmp;
                                 }
                                 double y0 = lo.y + t0 * ld.y;
-                                if (mn < y0 && y0 < mx) leaf_add<TRACK>(acc, t0);
+                                if (mn < y0 && y0 < mx) leaf_add(t0);
                                 double y1 = lo.y + t1 * ld.y;
-                                if (mn < y1 && y1 < mx) leaf_add<TRACK>(acc, t1);
+                                if (mn < y1 && y1 < mx) leaf_add(t1);
                             }
                         }
                         if (closed && !(fabs(ld.y) < RT_EPS)) {  // intersect_caps
@@ -518,11 +651,11 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                             double lim1 = cone ? fabs(mx) : 1.0;
                             double t0 = (mn - lo.y) / ld.y;
                             double x = lo.x + t0 * ld.x, z = lo.z + t0 * ld.z;
-                            if (((x * x) + (z * z)) <= lim0) leaf_add<TRACK>(acc, t0);
+                            if (((x * x) + (z * z)) <= lim0) leaf_add(t0);
                             double t1 = (mx - lo.y) / ld.y;
                             x = lo.x + t1 * ld.x;
                             z = lo.z + t1 * ld.z;
-                            if (((x * x) + (z * z)) <= lim1) leaf_add<TRACK>(acc, t1);
+                            if (((x * x) + (z * z)) <= lim1) leaf_add(t1);
                         }
                     }
                     break;
@@ -542,33 +675,14 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                             double v = f * dot(ld, origin_cross_e1);
                             if (!(v < 0.0 || (u + v) > 1.0)) {
                                 double t = f * dot(e2, origin_cross_e1);
-                                leaf_add<TRACK>(acc, t);  // u and v are recomputed when the hit is shaded
+                                leaf_add(t);  // u and v are recomputed when the hit is shaded
                             }
                         }
                     }
                     break;
                 }
             }
-            // Stable sorts keep depth-first order among equal times, so a later leaf only wins
-            // with a strictly smaller time (group.rs:147, world.rs:65).
-            if (acc.found && (!h.found || acc.best < h.t)) {
-                h.found = true;
-                h.t = acc.best;
-                h.node = rnode;
-                h.par = acc.par;
-            }
-            if (TRACK && acc.par) {
-                if (h.a_id < 0 || acc.negmax >= h.a_t) {
-                    h.b_t = h.a_t;
-                    h.b_id = h.a_id;
-                    h.a_t = acc.negmax;
-                    h.a_id = rnode;
-                } else if (h.b_id < 0 || acc.negmax >= h.b_t) {
-                    h.b_t = acc.negmax;
-                    h.b_id = rnode;
-                }
-            }
-            if (early && h.found && h.t < limit) skip_until = INT_MAX;  // this lane is decided
+            if (!CSGM || csg_depth == 0) commit_leaf();
         }
         i = i + 1;
         if (early && __ballot(i >= skip_until) == 0ull) {
@@ -798,7 +912,7 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, i
     local_y = lty * RT_TILE + (lane >> 3);
 }
 
-template <bool TRACK, bool XF, bool CULL>
+template <bool TRACK, bool XF, bool CULL, bool CSGM>
 __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters,
                                                  unsigned long long* __restrict__ clear_counters) {
@@ -858,7 +972,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
         unsigned long long pt = __builtin_amdgcn_s_memtime();
 #endif
-        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST, XF, CULL>(S, pending, ro, rd, 0.0, h);
+        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST, XF, CULL, CSGM>(S, pending, ro, rd, 0.0, h);
 #ifdef RT_PROFILE
         prof_closest += __builtin_amdgcn_s_memtime() - pt;
         prof_visits += h.visits;
@@ -1032,7 +1146,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
             unsigned long long ps = __builtin_amdgcn_s_memtime();
 #endif
-            trace<MODE_SHADOW, XF, CULL>(S, shade, over, lightv, distance, sh);
+            trace<MODE_SHADOW, XF, CULL, CSGM>(S, shade, over, lightv, distance, sh);
 #ifdef RT_PROFILE
             prof_shadow += __builtin_amdgcn_s_memtime() - ps;
             prof_visits += sh.visits;
@@ -1249,6 +1363,7 @@ struct rt_scene {
     bool any_transparent = false;
     bool any_xform = false;  // the traversal records include T_XFORM entries
     bool any_cull = false;   // ... and T_CULL entries
+    bool any_csg = false;    // ... and T_CSG_BEGIN / T_CSG_END pairs
     std::vector<void*> allocations;
     unsigned long long* d_counters = nullptr;  // two sets of COUNTER_WORDS, used by alternate launches
     bool set_clean[2] = {true, true};
@@ -1293,12 +1408,36 @@ int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
         auto bad = [&](const char* what) {
             return fail(RT_ERR_INVALID, "node " + std::to_string(i) + ": " + what);
         };
-        if (n.type < RT_GROUP || n.type > RT_SMOOTH_TRIANGLE) return bad("unknown type");
+        if (n.type < RT_GROUP || n.type > RT_CSG) return bad("unknown type");
+        const bool container = n.type == RT_GROUP || n.type == RT_CSG;
         if (n.parent < -1 || n.parent >= i) return bad("parent must precede the node");
-        if (n.parent >= 0 && d->nodes[n.parent].type != RT_GROUP) return bad("parent is not a group");
+        if (n.parent >= 0 && d->nodes[n.parent].type != RT_GROUP && d->nodes[n.parent].type != RT_CSG)
+            return bad("parent is not a group or CSG shape");
         if (n.skip <= i || n.skip > d->n_nodes) return bad("bad skip link");
         if (n.parent >= 0 && n.skip > d->nodes[n.parent].skip) return bad("subtree leaves its parent");
-        if (n.type != RT_GROUP && n.skip != i + 1) return bad("leaf with a subtree");
+        if (!container && n.skip != i + 1) return bad("leaf with a subtree");
+        if (n.type == RT_CSG) {
+            // exactly two operands: the next node and the one after its subtree (csg.rs:20-21)
+            if (i + 1 >= n.skip) return bad("CSG shape without operands");
+            const int right = d->nodes[i + 1].skip;
+            if (right <= i + 1 || right >= n.skip || right > d->n_nodes) return bad("CSG shape without a right operand");
+            if (d->nodes[right].skip != n.skip) return bad("CSG shape with more than two operands");
+            if (d->nodes[i + 1].parent != i || d->nodes[right].parent != i) return bad("CSG operand with a wrong parent");
+            int nest = 1;
+            for (int p = n.parent; p >= 0; p = d->nodes[p].parent)
+                if (d->nodes[p].type == RT_CSG) ++nest;
+            if (nest > RT_MAX_CSG_NEST) return fail(RT_ERR_LIMIT, "CSG shapes nested too deeply");
+            if (nest == 1) {  // outermost: every intersection of its leaves must fit the per-lane list
+                int most = 0;
+                for (int k = i + 1; k < n.skip && k < d->n_nodes; ++k) {
+                    const int t = d->nodes[k].type;
+                    most += (t == RT_SPHERE || t == RT_CUBE) ? 2 : (t == RT_CYLINDER || t == RT_CONE) ? 4
+                            : (t == RT_PLANE || t == RT_TRIANGLE || t == RT_SMOOTH_TRIANGLE) ? 1 : 0;
+                }
+                if (most > RT_MAX_CSG_HITS)
+                    return fail(RT_ERR_LIMIT, "a CSG shape can produce more than RT_MAX_CSG_HITS intersections per ray");
+            }
+        }
         if (n.xform < -1 || n.xform >= d->n_xforms) return bad("xform out of range");
         if (n.ctx < -1 || n.ctx >= i) return bad("ctx must precede the node");
         // ctx must be the nearest enclosing group with a transform
@@ -1314,6 +1453,7 @@ int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
         if (depth > RT_MAX_XFORM_NEST) return fail(RT_ERR_LIMIT, "transformed groups nested too deeply");
         switch (n.type) {
             case RT_GROUP:
+            case RT_CSG:
                 if (n.data < 0 || n.data >= d->n_aabbs) return bad("aabb out of range");
                 break;
             case RT_CYLINDER:
@@ -1327,7 +1467,7 @@ int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
             default:
                 break;
         }
-        if (n.type != RT_GROUP) {
+        if (!container) {
             if (n.material < 0 || n.material >= d->n_materials) return bad("material out of range");
             if (!(n.flags & RT_NODE_CASTS_SHADOW)) all_cast = false;
         }
@@ -1450,38 +1590,71 @@ bool cull_record(const rt_scene_desc* d, const rt_node& n, TRec& out) {
 
 // Lays the node table out as traversal records (see TRec).
 std::vector<TRec> build_records(const rt_scene_desc* d) {
+    const int N = d->n_nodes;
     std::vector<TRec> out;
-    std::vector<int> first(d->n_nodes + 1, 0);
-    // pass 1: record index of every node's first record
-    int count = 0;
-    for (int i = 0; i < d->n_nodes; ++i) {
-        const rt_node& n = d->nodes[i];
-        first[i] = count;
-        const bool own_payload = n.type == RT_GROUP || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
-        TRec probe{};
-        count += ((n.xform >= 0 && own_payload) || cull_record(d, n, probe)) ? 2 : 1;
+    // A CSG shape's end record follows its last descendant.  Several shapes can end at the same
+    // node index k (each the last child of the one before); their end records come innermost
+    // first.  A skip over node X must land after the end records of the CSG shapes inside X (or X
+    // itself) and before those of the shapes around X:
+    //   target(X) = pre[X.skip] + ends_inside[X]
+    // pre[k]: record index before the end records that close at k; rec[k]: first record of node k.
+    std::vector<int> last_child(N, -1), ends_inside(N, 0), closes(N + 1, 0), pre(N + 1, 0), rec(N + 1, 0);
+    for (int c = 0; c < N; ++c) {
+        const int p = d->nodes[c].parent;
+        if (p >= 0 && d->nodes[c].skip == d->nodes[p].skip) last_child[p] = c;
+        if (d->nodes[c].type == RT_CSG) ++closes[d->nodes[c].skip];
     }
-    first[d->n_nodes] = count;
-    out.reserve(count);
-    for (int i = 0; i < d->n_nodes; ++i) {
+    for (int x = N - 1; x >= 0; --x)
+        ends_inside[x] = (d->nodes[x].type == RT_CSG ? 1 : 0) + (last_child[x] >= 0 ? ends_inside[last_child[x]] : 0);
+    auto own_payload = [&](const rt_node& n) {
+        return n.type == RT_GROUP || n.type == RT_CSG || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
+    };
+    int count = 0;
+    for (int i = 0; i < N; ++i) {
         const rt_node& n = d->nodes[i];
-        const bool own_payload = n.type == RT_GROUP || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
+        pre[i] = count;
+        count += closes[i];
+        rec[i] = count;
+        TRec probe{};
+        count += ((n.xform >= 0 && own_payload(n)) || cull_record(d, n, probe)) ? 2 : 1;
+    }
+    pre[N] = count;
+    count += closes[N];
+    rec[N] = count;
+    out.reserve(count);
+    std::vector<int> open;  // CSG shapes whose end record is still to come
+    auto close_until = [&](int k) {
+        while (!open.empty() && d->nodes[open.back()].skip == k) {
+            const int c = open.back();
+            open.pop_back();
+            const rt_node& n = d->nodes[c];
+            TRec e{};
+            e.kind = T_CSG_END | (((n.flags & RT_NODE_CSG_OP_MASK) >> 4) << T_CSG_OP_SHIFT);
+            e.node = c;
+            e.skip = d->nodes[c + 1].skip;  // node index where the right operand starts
+            e.ctx = n.xform >= 0 ? rec[c] : (n.ctx >= 0 ? rec[n.ctx] : -1);
+            out.push_back(e);
+        }
+    };
+    for (int i = 0; i < N; ++i) {
+        close_until(i);
+        const rt_node& n = d->nodes[i];
         TRec r{};
-        r.skip = first[n.skip];
-        r.ctx = n.ctx >= 0 ? first[n.ctx] : -1;
+        r.skip = pre[n.skip] + ends_inside[i];
+        r.ctx = n.ctx >= 0 ? rec[n.ctx] : -1;
         r.node = i;
         int flags = (n.flags & RT_NODE_CLOSED) ? T_CLOSED : 0;
-        if (n.xform >= 0 && own_payload) {
+        if (n.xform >= 0 && own_payload(n)) {
             TRec x = r;
             x.kind = T_XFORM | T_HAS_INV;
             std::memcpy(x.p, d->xforms[n.xform].inv, sizeof x.p);
             out.push_back(x);
             flags |= T_OWN_XFORM;
-            r.ctx = first[i];  // the node itself is tested in its own space
+            r.ctx = rec[i];  // the node itself is tested in its own space
         } else {
             TRec c = r;
             if (cull_record(d, n, c)) {
-                c.skip = first[i] + 2;  // past the leaf
+                c.skip = rec[i] + 2;  // past the leaf
                 out.push_back(c);
             }
             if (n.xform >= 0) {
@@ -1489,10 +1662,11 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
                 std::memcpy(r.p, d->xforms[n.xform].inv, sizeof r.p);
             }
         }
-        r.kind = n.type | flags;
-        if (n.type == RT_GROUP) {
+        r.kind = (n.type == RT_CSG ? (int)T_CSG_BEGIN : n.type) | flags;
+        if (n.type == RT_GROUP || n.type == RT_CSG) {
             std::memcpy(r.p, d->aabbs[n.data].min, 3 * sizeof(double));
             std::memcpy(r.p + 3, d->aabbs[n.data].max, 3 * sizeof(double));
+            if (n.type == RT_CSG) open.push_back(i);
         } else if (n.type == RT_CYLINDER || n.type == RT_CONE) {
             r.r0 = d->ranges[n.data].minimum;
             r.r1 = d->ranges[n.data].maximum;
@@ -1503,6 +1677,7 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
         }
         out.push_back(r);
     }
+    close_until(N);
     return out;
 }
 
@@ -1535,7 +1710,7 @@ std::vector<SRec> build_shade_records(const rt_scene_desc* d) {
             std::memcpy(r.inv, d->xforms[n.xform].inv, sizeof r.inv);
             std::memcpy(r.inv_t, d->xforms[n.xform].inv_t, sizeof r.inv_t);
         }
-        if (n.type != RT_GROUP) {
+        if (n.type != RT_GROUP && n.type != RT_CSG) {
             const rt_material& m = d->materials[n.material];
             r.ka = m.ambient;
             r.kd = m.diffuse;
@@ -1586,11 +1761,14 @@ int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipSt
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (blocks > 0) {
         using Kernel = void (*)(DevScene, DevJob, double*, unsigned long long*, unsigned long long*);
-        static const Kernel kernels[8] = {rt_kernel<false, false, false>, rt_kernel<false, false, true>,
-                                          rt_kernel<false, true, false>,  rt_kernel<false, true, true>,
-                                          rt_kernel<true, false, false>,  rt_kernel<true, false, true>,
-                                          rt_kernel<true, true, false>,   rt_kernel<true, true, true>};
+        static const Kernel kernels[8] = {
+            rt_kernel<false, false, false, false>, rt_kernel<false, false, true, false>,
+            rt_kernel<false, true, false, false>,  rt_kernel<false, true, true, false>,
+            rt_kernel<true, false, false, false>,  rt_kernel<true, false, true, false>,
+            rt_kernel<true, true, false, false>,   rt_kernel<true, true, true, false>};
         Kernel kernel = kernels[(s->any_transparent ? 4 : 0) | (s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
+        // scenes with CSG shapes are rare: they share the two most general variants
+        if (s->any_csg) kernel = s->any_transparent ? rt_kernel<true, true, true, true> : rt_kernel<false, true, true, true>;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, mine,
                            clears_other ? other : nullptr);
         HIP_TRY(hipGetLastError());
@@ -1675,6 +1853,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         for (const TRec& r : recs)
             if ((r.kind & 0xff) == T_XFORM) s->any_xform = true;
             else if ((r.kind & 0xff) == T_CULL) s->any_cull = true;
+            else if ((r.kind & 0xff) == T_CSG_BEGIN) s->any_csg = true;
     }
     if ((rc = upload(s, d->nodes, d->n_nodes, &s->dev.nodes)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms)) != RT_OK) return cleanup(rc);
