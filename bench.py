@@ -205,7 +205,9 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s scene (src/lib.rs build_world), %dx%d, depth 5" % (args.workload, W, H),
+                "workload": "%s scene%s, %dx%d, depth %d" % (
+                    args.workload, " (src/lib.rs build_world)" if args.workload == "default" else " (raytracer_amd/scenes.py)",
+                    W, H, args.max_depth),
                 "rays_per_frame": int(rays),
                 "partition": "cyclic 8-row tiles over %d rank(s)%s" % (
                     world_size,

@@ -176,10 +176,42 @@ def mesh_camera(api, width, height):
                                        api.vector(0.0, 1.0, 0.0)))
 
 
+def csg_world(api):
+    """Constructive solid geometry (src/geometry/csg.rs): a die (cube ∩ sphere, minus three
+    cylinders through its faces), a glass lens (sphere ∩ sphere) and a union of a cone and a sphere,
+    on a checkered floor.  Build-defined (the reference's binary renders no CSG shape); its oracle
+    is the CPU restatement."""
+    M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+    floor = api.Plane(M.identity(),
+                      Phong(api.Checker(Solid(Color.white()), Solid(Color(0.2, 0.2, 0.25)), M.identity()),
+                            0.1, 0.9, 0.0, 200.0, 0.2, 0.0, 1.0), True)
+    ivory = Phong(Solid(Color(0.9, 0.85, 0.7)), 0.1, 0.8, 0.4, 80.0, 0.05, 0.0, 1.0)
+    red = Phong(Solid(Color(0.8, 0.1, 0.1)), 0.1, 0.8, 0.3, 50.0, 0.0, 0.0, 1.0)
+    body = api.CSG(api.INTERSECTION, api.Cube(M.identity(), ivory, True),
+                   api.Sphere(M.scaling(1.4, 1.4, 1.4), ivory, True))
+    bores = api.Group()
+    for rot in (M.identity(), M.rotation_x(math.pi / 2.0), M.rotation_z(math.pi / 2.0)):
+        bores.add_child(api.Cylinder(rot * M.scaling(0.45, 1.0, 0.45), red, True, -1.5, 1.5, True))
+    die = api.CSG(api.DIFFERENCE, body, bores,
+                  M.translation(-1.6, 1.0, 0.0) * M.rotation_y(0.6) * M.rotation_x(0.3))
+    glass = Phong(Solid(Color(0.05, 0.08, 0.05)), 0.0, 0.1, 1.0, 300.0, 0.6, 0.9, 1.5)
+    lens = api.CSG(api.INTERSECTION, api.Sphere(M.translation(0.0, 0.0, -0.6), glass, True),
+                   api.Sphere(M.translation(0.0, 0.0, 0.6), glass, True),
+                   M.translation(1.4, 1.0, -1.0) * M.rotation_y(-0.4))
+    blue = Phong(Solid(Color(0.2, 0.3, 0.9)), 0.1, 0.8, 0.5, 100.0, 0.1, 0.0, 1.0)
+    top = api.CSG(api.UNION, api.Cone(M.translation(0.0, 1.0, 0.0), blue, True, -1.0, 0.0, True),
+                  api.Sphere(M.translation(0.0, 1.0, 0.0) * M.scaling(0.4, 0.4, 0.4), blue, True),
+                  M.translation(2.2, 0.0, 2.0))
+    lights = [api.PointLight(api.point(-8.0, 10.0, -8.0), Color.white()),
+              api.PointLight(api.point(6.0, 6.0, -4.0), Color(0.3, 0.3, 0.3))]
+    return api.World([floor, die, lens, top], lights)
+
+
 WORKLOADS = {
     "default": (build_world, default_camera),
     "glass": (glass_world, glass_camera),
     "teapot": (lambda api: mesh_world(api, "teapot"), mesh_camera),
     "smooth_teapot": (lambda api: mesh_world(api, "smooth_teapot"), mesh_camera),
     "dragon": (lambda api: mesh_world(api, "dragon"), mesh_camera),
+    "csg": (csg_world, glass_camera),
 }

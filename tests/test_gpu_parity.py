@@ -37,6 +37,7 @@ def check(img, ref, tol=1e-11):
     ("glass", (160, 90)),
     ("teapot", (96, 96)),
     ("smooth_teapot", (96, 96)),
+    ("csg", (200, 120)),
 ])
 def test_render_matches_oracle(host, orc, name, size):
     W, H = size
