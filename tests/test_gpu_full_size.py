@@ -1,0 +1,72 @@
+"""The measured configurations at their full sizes.  The oracle cannot render 8 or 33 million pixels
+in a test, so parity is checked on a random sample of pixels (each traced by the oracle through
+Camera::ray_for_pixel and World::color_at) plus whole-frame properties that do not depend on the
+size: the clamped-byte output equals Canvas::clamp of the f64 output everywhere, and the frame
+assembled from cyclic row tiles of several ranks equals the single-rank frame bit for bit."""
+import numpy as np
+import pytest
+
+from raytracer_amd import scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def sampled_reference(orc, world, cam, xs, ys):
+    o = np.empty((len(xs), 3))
+    d = np.empty((len(xs), 3))
+    for k, (x, y) in enumerate(zip(xs, ys)):
+        ray = orc.ray_for_pixel(cam, int(x), int(y))
+        o[k] = ray.origin[:3]
+        d[k] = ray.direction[:3]
+    return orc.color_at_batch(world, o, d, remaining=5)
+
+
+def quantise(img):
+    return np.clip(np.ceil(255.0 * img), 0, 255).astype(np.int64)
+
+
+def test_default_scene_3840x2160(host, orc):
+    W, H = 3840, 2160
+    img, st = host.render(scenes.build_world(host), scenes.default_camera(host, W, H), stats=True)
+    assert img.shape == (H, W, 3) and np.isfinite(img).all()
+    assert st.rays_primary == W * H
+    rng = np.random.default_rng(7)
+    n = 4000
+    xs, ys = rng.integers(0, W, n), rng.integers(0, H, n)
+    # the glass sphere is where the deep recursion happens: oversample its neighbourhood
+    xs[: n // 2] = rng.integers(int(0.35 * W), int(0.65 * W), n // 2)
+    ys[: n // 2] = rng.integers(int(0.25 * H), int(0.75 * H), n // 2)
+    ref = sampled_reference(orc, scenes.build_world(orc), scenes.default_camera(orc, W, H), xs, ys)
+    got = img[ys, xs]
+    assert np.abs(got - ref).max() <= 1e-11
+    assert (quantise(got) != quantise(ref)).sum() == 0
+    # bytes = Canvas::clamp of the colours, everywhere
+    img8 = host.render_u8(scenes.build_world(host), scenes.default_camera(host, W, H))
+    assert np.array_equal(img8, quantise(img).astype(np.uint8))
+
+
+def test_8k_frame_from_eight_ranks(host, orc):
+    """7680x4320 as the multi-GPU runs partition it: each of 8 ranks renders its cyclic 8-row tiles;
+    a sample of pixels from every rank's rows is checked against the oracle, and two ranks' buffers
+    are compared bit for bit with the corresponding rows of a 2-rank partition."""
+    W, H = 7680, 4320
+    world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
+    oworld, ocam = scenes.build_world(orc), scenes.default_camera(orc, W, H)
+    rng = np.random.default_rng(11)
+    parts = {}
+    for rank in (0, 3, 7):
+        part = host.render(world, cam, rank=rank, world_size=8)
+        rows = host.global_rows(H, rank, 8)
+        assert part.shape == (len(rows), W, 3)
+        parts[rank] = (part, rows)
+        k = rng.integers(0, len(rows), 500)
+        xs = rng.integers(0, W, 500)
+        ref = sampled_reference(orc, oworld, ocam, xs, rows[k])
+        assert np.abs(part[k, xs] - ref).max() <= 1e-11
+    # rank 0 of 8 owns tiles 0, 8, 16, ...; rank 0 of 2 owns tiles 0, 2, 4, ...: shared rows must agree exactly
+    half = host.render(world, cam, rank=0, world_size=2)
+    half_rows = host.global_rows(H, 0, 2)
+    part, rows = parts[0]
+    pos = {int(r): i for i, r in enumerate(half_rows)}
+    idx = np.array([pos[int(r)] for r in rows])
+    assert np.array_equal(half[idx], part)
