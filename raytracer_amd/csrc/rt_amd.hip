@@ -39,6 +39,8 @@
 #define RT_PAT_STACK (RT_MAX_PATTERN_NEST + 1)
 #define COUNTER_SHARDS 1024u  // each shard is 16 u64 (one 128-byte line)
 #define COUNTER_WORDS (COUNTER_SHARDS * 16u)
+// One more line per set: tile counts per cost class for the dispatch order (words 0..2).
+#define COUNTER_SET_WORDS (COUNTER_WORDS + 64u)
 
 namespace {
 
@@ -115,6 +117,8 @@ struct DevJob {
     int xcd_remap;
     int wide_stores;  // f64 output: base 16-byte aligned and even width; u8 output: base 4-byte aligned and width % 4 == 0
     int out_u8;       // the output is 3 bytes per pixel, quantised like Canvas::clamp, instead of 3 doubles
+    const int* tile_order;  // three arrays of tiles_x * local_tile_rows tile indices, one per cost class, or null
+    const unsigned long long* tile_class_count;  // how many tiles each class holds
     // ray-list mode (rt_color_at)
     long long n_rays;
     const double* ray_o;
@@ -895,6 +899,62 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
 #define RT_BLOCK_WAVES 1  // wavefronts (8x8 tiles) per workgroup; one gives the dispatcher the finest grain
 #endif
 #define RT_BLOCK (RT_BLOCK_WAVES * 64)
+// Camera::ray_for_pixel (camera.rs:47-66)
+DI void primary_ray(const DevJob& J, int px, int py, V3& ro, V3& rd) {
+    double x_offset = ((double)px + 0.5) * J.pixel_size;
+    double y_offset = ((double)py + 0.5) * J.pixel_size;
+    double world_x = J.half_width - x_offset;
+    double world_y = J.half_height - y_offset;
+    V3 pixel = xpoint(J.inv, mk(world_x, world_y, -1.0));
+    V3 origin = mk(J.inv[3], J.inv[7], J.inv[11]);
+    V3 dirv = pixel - origin;
+    double m = magnitude(dirv);
+    ro = origin;
+    rd = dirv / m;
+}
+
+// Dispatch order.  Workgroups start in index order and the frame ends when the last wavefront
+// does; if the expensive tiles (deep reflection / refraction recursion) come last the GPU drains
+// while a few long wavefronts finish.  A pre-pass traces the centre ray of every tile and puts
+// the tile in a cost class by what that ray hits (2 transparent, 1 reflective, 0 neither or
+// nothing); the render kernel then takes the tiles class 2 first.  This only permutes the order
+// in which tiles are rendered.
+template <bool XF, bool CULL, bool CSGM>
+__global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, long long n_tiles, int* __restrict__ order,
+                                                        unsigned long long* __restrict__ class_count) {
+    const int lane = threadIdx.x;
+    const long long tile = (long long)blockIdx.x * 64 + lane;
+    const bool active = tile < n_tiles;
+    const long long tt = active ? tile : 0;
+    const int tx = (int)(tt % J.tiles_x), lty = (int)(tt / J.tiles_x);
+    int px = tx * RT_TILE + RT_TILE / 2, py = (lty * J.world_size + J.rank) * RT_TILE + RT_TILE / 2;
+    px = px < J.width ? px : J.width - 1;
+    py = py < J.height ? py : J.height - 1;
+    V3 ro, rd;
+    primary_ray(J, px, py, ro, rd);
+    Hit h;
+    trace<MODE_CLOSEST, XF, CULL, CSGM>(S, active, ro, rd, 0.0, h);
+    int cls = 0;
+    if (active && h.found) {
+        const RT_CONST SRec* sr = S.shade + h.node;
+        cls = sr->transp != 0.0 ? 2 : (sr->refl != 0.0 ? 1 : 0);
+    }
+    // order holds one array of n_tiles entries per class; one atomic per wavefront and class, the
+    // lanes of a class take consecutive positions
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const unsigned long long mask = __ballot(active && cls == c);
+        if (mask != 0ull) {
+            const int leader = (int)__builtin_ctzll(mask);
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(&class_count[c], (unsigned long long)__builtin_popcountll(mask));
+            base = (unsigned long long)__shfl((long long)base, leader, 64);
+            if (active && cls == c)
+                order[(long long)c * n_tiles + (long long)base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int)tile;
+        }
+    }
+}
+
 // Pixel of this lane: column, row within this rank's compact buffer, and local tile row.
 // Workgroups are dealt round-robin to the 8 XCDs; the optional remap gives each XCD a contiguous
 // band of tiles.  Cheap enough to evaluate twice instead of holding the result in registers.
@@ -905,7 +965,14 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, i
         unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
         b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const long long tile = (long long)b * RT_BLOCK_WAVES + wave;
+    long long tile = (long long)b * RT_BLOCK_WAVES + wave;
+    const long long n_tiles = (long long)J.tiles_x * J.local_tile_rows;
+    if (J.tile_order && tile < n_tiles) {
+        // expensive classes first: class 2, then 1, then 0
+        const long long n2 = (long long)J.tile_class_count[2], n1 = (long long)J.tile_class_count[1];
+        tile = tile < n2 ? J.tile_order[2 * n_tiles + tile]
+                         : (tile < n2 + n1 ? J.tile_order[n_tiles + (tile - n2)] : J.tile_order[tile - n2 - n1]);
+    }
     const int tx = (int)(tile % J.tiles_x);
     lty = (int)(tile / J.tiles_x);
     px = tx * RT_TILE + (lane & 7);
@@ -920,7 +987,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
     const int wave = threadIdx.x >> 6;
     // The scene keeps two sets of ray counters; this launch clears the set the next launch will
     // use, which saves a memset (and its launch gap) per frame.
-    if (clear_counters && blockIdx.x < COUNTER_WORDS / RT_BLOCK) clear_counters[blockIdx.x * RT_BLOCK + threadIdx.x] = 0ull;
+    if (clear_counters && blockIdx.x < COUNTER_SET_WORDS / RT_BLOCK) clear_counters[blockIdx.x * RT_BLOCK + threadIdx.x] = 0ull;
     // A lane parks its finished pixel in LDS instead of carrying it through the rest of the
     // wavefront's rounds; the tile is written from there at the end.
     __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
@@ -943,17 +1010,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
         lane_pixel(J, wave, lane, px, local_y, lty);
         const int py = (lty * J.world_size + J.rank) * RT_TILE + (lane >> 3);
         pending = lty < J.local_tile_rows && px < J.width && py < J.height;
-        // Camera::ray_for_pixel (camera.rs:47-66)
-        double x_offset = ((double)px + 0.5) * J.pixel_size;
-        double y_offset = ((double)py + 0.5) * J.pixel_size;
-        double world_x = J.half_width - x_offset;
-        double world_y = J.half_height - y_offset;
-        V3 pixel = xpoint(J.inv, mk(world_x, world_y, -1.0));
-        V3 origin = mk(J.inv[3], J.inv[7], J.inv[11]);
-        V3 dirv = pixel - origin;
-        double m = magnitude(dirv);
-        ro = origin;
-        rd = dirv / m;
+        primary_ray(J, px, py, ro, rd);
     }
     const bool valid = pending;
 
@@ -1364,8 +1421,14 @@ struct rt_scene {
     bool any_xform = false;  // the traversal records include T_XFORM entries
     bool any_cull = false;   // ... and T_CULL entries
     bool any_csg = false;    // ... and T_CSG_BEGIN / T_CSG_END pairs
+    // The dispatch-order pre-pass pays when tiles differ in recursion depth (materials of more than
+    // one cost class) and its own rays are cheap (a short record array; its few hundred wavefronts
+    // of incoherent rays would crawl through a mesh).
+    bool order_useful = false;
     std::vector<void*> allocations;
-    unsigned long long* d_counters = nullptr;  // two sets of COUNTER_WORDS, used by alternate launches
+    unsigned long long* d_counters = nullptr;  // two sets of COUNTER_SET_WORDS, used by alternate launches
+    int* d_order = nullptr;                     // tiles of the current frame by cost class (3 arrays)
+    long long order_cap = 0;
     bool set_clean[2] = {true, true};
     int next_set = 0, last_set = 0;
     double* d_frame = nullptr;  // staging for the synchronous entry points
@@ -1750,15 +1813,43 @@ int local_tile_rows(int height, const rt_params* p) {
     return (tile_rows - p->rank + p->world_size - 1) / p->world_size;
 }
 
-int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipStream_t stream) {
+// Frames with at least this many tiles are rendered expensive tiles first (see tile_class_kernel).
+constexpr long long ORDER_MIN_TILES = 4096;
+
+int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t stream) {
     int slot = (int)(s->launches % TIMING_RING);
     // Launches on one scene must be ordered (one stream at a time): each clears the other counter set.
     const int a = s->next_set, b = a ^ 1;
-    unsigned long long* mine = s->d_counters + (size_t)a * COUNTER_WORDS;
-    unsigned long long* other = s->d_counters + (size_t)b * COUNTER_WORDS;
-    if (!s->set_clean[a]) HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_WORDS * sizeof(unsigned long long), stream));
-    const bool clears_other = blocks >= COUNTER_WORDS / RT_BLOCK;
+    unsigned long long* mine = s->d_counters + (size_t)a * COUNTER_SET_WORDS;
+    unsigned long long* other = s->d_counters + (size_t)b * COUNTER_SET_WORDS;
+    if (!s->set_clean[a]) HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), stream));
+    const bool clears_other = blocks >= COUNTER_SET_WORDS / RT_BLOCK;
+    const long long tiles = job.n_rays > 0 ? 0 : (long long)job.tiles_x * job.local_tile_rows;
+    static const bool order_enabled = !(getenv("RT_TILE_ORDER") && atoi(getenv("RT_TILE_ORDER")) == 0);
+    job.tile_order = nullptr;
+    if (order_enabled && s->order_useful && tiles >= ORDER_MIN_TILES) {
+        if (tiles > s->order_cap) {
+            if (s->d_order) HIP_TRY(hipFree(s->d_order));
+            s->d_order = nullptr;
+            s->order_cap = 0;
+            HIP_TRY(hipMalloc((void**)&s->d_order, 3 * (size_t)tiles * sizeof(int)));
+            s->order_cap = tiles;
+        }
+        job.tile_order = s->d_order;
+        job.tile_class_count = mine + COUNTER_WORDS;
+    }
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
+    if (job.tile_order) {
+        DevJob pre = job;
+        pre.tile_order = nullptr;
+        using Pre = void (*)(DevScene, DevJob, long long, int*, unsigned long long*);
+        static const Pre pres[4] = {tile_class_kernel<false, false, false>, tile_class_kernel<false, true, false>,
+                                    tile_class_kernel<true, false, false>, tile_class_kernel<true, true, false>};
+        Pre prek = s->any_csg ? tile_class_kernel<true, true, true> : pres[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
+        hipLaunchKernelGGL(prek, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, s->dev, pre, tiles, s->d_order,
+                           mine + COUNTER_WORDS);
+        HIP_TRY(hipGetLastError());
+    }
     if (blocks > 0) {
         using Kernel = void (*)(DevScene, DevJob, double*, unsigned long long*, unsigned long long*);
         static const Kernel kernels[8] = {
@@ -1786,7 +1877,7 @@ int launch(rt_scene* s, const DevJob& job, unsigned blocks, double* d_out, hipSt
 int fill_stats(rt_scene* s, rt_stats* st) {
     if (!st) return RT_OK;
     std::vector<unsigned long long> shards(COUNTER_SHARDS * 16);
-    HIP_TRY(hipMemcpy(shards.data(), s->d_counters + (size_t)s->last_set * COUNTER_WORDS,
+    HIP_TRY(hipMemcpy(shards.data(), s->d_counters + (size_t)s->last_set * COUNTER_SET_WORDS,
                       shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long c[16] = {};
     for (unsigned k = 0; k < COUNTER_SHARDS; ++k)
@@ -1850,6 +1941,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         std::vector<TRec> recs = build_records(d);
         if ((rc = upload(s, recs.data(), recs.size(), &s->dev.trav)) != RT_OK) return cleanup(rc);
         s->dev.n_trav = (int)recs.size();
+        bool cls[3] = {false, false, false};
+        for (int i = 0; i < d->n_nodes; ++i)
+            if (d->nodes[i].type != RT_GROUP && d->nodes[i].type != RT_CSG) {
+                const rt_material& m = d->materials[d->nodes[i].material];
+                cls[m.transparency != 0.0 ? 2 : (m.reflective != 0.0 ? 1 : 0)] = true;
+            }
+        s->order_useful = recs.size() <= 1024 && (int)cls[0] + (int)cls[1] + (int)cls[2] > 1;
         for (const TRec& r : recs)
             if ((r.kind & 0xff) == T_XFORM) s->any_xform = true;
             else if ((r.kind & 0xff) == T_CULL) s->any_cull = true;
@@ -1874,10 +1972,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(d->aabbs[i].min[k]) || !std::isfinite(d->aabbs[i].max[k])) s->dev.finite_bounds = 0;
     void* p = nullptr;
-    if (hipMalloc(&p, 2 * COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMalloc(&p, 2 * COUNTER_SET_WORDS * sizeof(unsigned long long)) != hipSuccess)
         return cleanup(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
     s->d_counters = (unsigned long long*)p;
-    if (hipMemset(p, 0, 2 * COUNTER_WORDS * sizeof(unsigned long long)) != hipSuccess)
+    if (hipMemset(p, 0, 2 * COUNTER_SET_WORDS * sizeof(unsigned long long)) != hipSuccess)
         return cleanup(fail(RT_ERR_HIP, "hipMemset(counters) failed"));
     for (int i = 0; i < TIMING_RING; ++i) {
         if (hipEventCreate(&s->ev_start[i]) != hipSuccess || hipEventCreate(&s->ev_stop[i]) != hipSuccess)
@@ -1893,6 +1991,7 @@ void rt_scene_destroy(rt_scene* s) {
     (void)hipDeviceSynchronize();
     for (void* p : s->allocations) (void)hipFree(p);
     if (s->d_counters) (void)hipFree(s->d_counters);
+    if (s->d_order) (void)hipFree(s->d_order);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->d_rays) (void)hipFree(s->d_rays);
     for (int i = 0; i < TIMING_RING; ++i) {
