@@ -385,23 +385,22 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             leaf_count<TRACK>(acc, t);
         }
     };
+    // Written as selects, not branches: the hit state then stays in place across the loop instead of
+    // being copied around the join points of every leaf visit.
     auto commit_leaf = [&]() {
-        if (acc.found && (!h.found || acc.best < h.t)) {
-            h.found = true;
-            h.t = acc.best;
-            h.node = acc_node;
-            h.par = acc.par;
-        }
-        if (TRACK && acc.par) {
-            if (h.a_id < 0 || acc.negmax >= h.a_t) {
-                h.b_t = h.a_t;
-                h.b_id = h.a_id;
-                h.a_t = acc.negmax;
-                h.a_id = acc_node;
-            } else if (h.b_id < 0 || acc.negmax >= h.b_t) {
-                h.b_t = acc.negmax;
-                h.b_id = acc_node;
-            }
+        const bool better = acc.found && (!h.found || acc.best < h.t);
+        h.found = h.found || acc.found;
+        h.t = better ? acc.best : h.t;
+        h.node = better ? acc_node : h.node;
+        h.par = better ? acc.par : h.par;
+        if (TRACK) {
+            const bool odd = acc.par != 0;
+            const bool first = odd && (h.a_id < 0 || acc.negmax >= h.a_t);
+            const bool second = odd && !first && (h.b_id < 0 || acc.negmax >= h.b_t);
+            h.b_t = first ? h.a_t : (second ? acc.negmax : h.b_t);
+            h.b_id = first ? h.a_id : (second ? acc_node : h.b_id);
+            h.a_t = first ? acc.negmax : h.a_t;
+            h.a_id = first ? acc_node : h.a_id;
         }
         if (early && h.found && h.t < limit) skip_until = INT_MAX;  // this lane is decided
     };
@@ -686,8 +685,10 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     break;
                 }
             }
-            if (!CSGM || csg_depth == 0) commit_leaf();
         }
+        // outside the divergent region on purpose: lanes that skipped the leaf have an empty
+        // accumulator, and the hit state is not duplicated around the branch
+        if (!CSGM || csg_depth == 0) commit_leaf();
         i = i + 1;
         if (early && __ballot(i >= skip_until) == 0ull) {
             i = wave_min(skip_until);  // INT_MAX when every lane is decided: the loop ends
