@@ -104,6 +104,7 @@ struct DevScene {
     int n_lights;
     int all_cast_shadow;
     int finite_bounds;  // every group box is finite (no plane inside a group)
+    double prune_base;  // 1 + the largest |coordinate| of any group box; infinite when a box is
 };
 
 struct DevJob {
@@ -257,12 +258,23 @@ DI double reciprocal1(double d) { return fabs(d) >= RT_EPS ? rcp_exact(d) : __bu
 DI V3 reciprocal(V3 d) { return mk(reciprocal1(d.x), reciprocal1(d.y), reciprocal1(d.z)); }
 
 // Slack, in ray-time units, for pruning subtrees by their box times: a child's computed time can
-// differ from the box times of its group by rounding, which grows with the square of the origin's
-// distance (cancellation in the quadratics) and with 1/|direction| (time per unit length).
-DI double prune_margin(double origin_sq, V3 rcp_dir) {
+// differ from the box times of its group by rounding.  Times are at most about
+// (|origin| + extent) / |direction| and carry a few ulps of that; cancellation in the quadratics
+// adds a term that grows with |origin|^2.  base = 1 + extent of the group boxes.
+DI double prune_margin(double base, double origin_sq, V3 rcp_dir) {
     double r = fmax(fmax(fabs(rcp_dir.x), fabs(rcp_dir.y)), fabs(rcp_dir.z));  // NaN components are ignored
-    double m = (1e-9 * (1.0 + origin_sq)) * r;
+    double m = (1e-9 * (base + origin_sq)) * r;
     return (m == m) ? m : INFINITY;  // no finite reciprocal at all: never prune
+}
+// The slab times through the reciprocals without the correction step of div_by: each is within
+// 1.5 ulp of the exact quotient, which decides tmin > tmax unless the two are that close.
+DI void slabs_near(V3 o, V3 y, double x0, double y0, double z0, double x1, double y1, double z1, double& tmin,
+                   double& tmax) {
+    double ax = (x0 - o.x) * y.x, bx = (x1 - o.x) * y.x;
+    double ay = (y0 - o.y) * y.y, by = (y1 - o.y) * y.y;
+    double az = (z0 - o.z) * y.z, bz = (z1 - o.z) * y.z;
+    tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
+    tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
 }
 
 // Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
@@ -356,7 +368,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     V3 co = wo, cd = wd;  // the ray in the space of the transformed group `cur_ctx`
     V3 cy = reciprocal(cd);  // exact reciprocals of cd, used by the fast slab test
     double coo = dot(co, co);   // scales the padding of T_CULL boxes
-    double tpad = prune_margin(coo, cy);
+    double tpad = prune_margin(S.prune_base, coo, cy);
     bool cfin = all_axes_finite(cd);
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
     int csg_depth = 0;  // open CSG shapes around the current record (wave-uniform)
@@ -435,7 +447,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             chain_ray(S, ctx, co, cd);
             cy = reciprocal(cd);
             coo = dot(co, co);
-            tpad = prune_margin(coo, cy);
+            tpad = prune_margin(S.prune_base, coo, cy);
             cfin = all_axes_finite(cd);
             cur_ctx = ctx;
         }
@@ -448,7 +460,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             cd = td;
             cy = reciprocal(cd);
             coo = dot(co, co);
-            tpad = prune_margin(coo, cy);
+            tpad = prune_margin(S.prune_base, coo, cy);
             cfin = all_axes_finite(cd);
             cur_ctx = i;
             i = i + 1;
@@ -544,10 +556,16 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // Group::local_intersect (group.rs:133-154) and CSG::local_intersect (csg.rs:145):
             // bounds test in the shape's own space.
             double tmin, tmax;
-            if (S.finite_bounds && __ballot(act && !cfin) == 0ull)
-                slabs_fast(co, cd, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
-            else
+            if (S.finite_bounds && __ballot(act && !cfin) == 0ull) {
+                // The uncorrected quotients decide almost every lane; the exact ones are only
+                // computed when some lane's tmin and tmax are within a few ulps of each other.
+                slabs_near(co, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
+                const bool close = fabs(tmax - tmin) <= 2e-15 * (fabs(tmin) + fabs(tmax));
+                if (__ballot(act && close) != 0ull)
+                    slabs_fast(co, cd, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
+            } else {
                 slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
+            }
             bool inside = act && !(tmin > tmax);
             // The reference enters every group whose box the ray's LINE meets.  Subtrees that can
             // only yield times that do not count are skipped: behind the origin (unless the n1/n2
@@ -1969,9 +1987,14 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     s->dev.n_lights = d->n_lights;
     s->dev.all_cast_shadow = all_cast ? 1 : 0;
     s->dev.finite_bounds = 1;
+    double extent = 0.0;
     for (int i = 0; i < d->n_aabbs; ++i)
         for (int k = 0; k < 3; ++k)
+        {
             if (!std::isfinite(d->aabbs[i].min[k]) || !std::isfinite(d->aabbs[i].max[k])) s->dev.finite_bounds = 0;
+            extent = std::fmax(extent, std::fmax(std::fabs(d->aabbs[i].min[k]), std::fabs(d->aabbs[i].max[k])));
+        }
+    s->dev.prune_base = s->dev.finite_bounds ? 1.0 + extent : INFINITY;
     void* p = nullptr;
     if (hipMalloc(&p, 2 * COUNTER_SET_WORDS * sizeof(unsigned long long)) != hipSuccess)
         return cleanup(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));

@@ -260,3 +260,41 @@ def test_culling_is_conservative(host, orc, seed):
     err = np.abs(got[finite] - ref[finite]) / np.maximum(1.0, np.abs(ref[finite]))
     assert err.max() <= 1e-9, "seed %d: max rel err %.3e" % (seed, err.max())
     assert (ref[finite] != 0.0).any()
+
+
+def test_rays_through_group_box_edges(host, orc):
+    """The group bounds test (group.rs:139, bounding_box.rs:80-98) decides by tmin > tmax.  The device
+    first compares uncorrected quotients and only falls back to the exact ones when they are within
+    a few ulps; rays through the edges and corners of a group's box (where tmin == tmax up to
+    rounding) must still take the reference's side of every such tie."""
+    def world(o):
+        M = o.Matrix
+        g = o.Group()
+        g.add_child(o.Cube(M.translation(0.3, -0.2, 0.1) * M.scaling(1.3, 0.7, 0.9),
+                           o.Phong(o.Solid(o.Color(0.9, 0.2, 0.2)), 0.3, 0.7, 0.0, 200.0, 0.0, 0.0, 1.0), True))
+        g.add_child(o.Sphere(M.translation(0.3, -0.2, 0.1) * M.scaling(0.5, 0.5, 0.5),
+                             o.Phong(o.Solid(o.Color(0.2, 0.9, 0.2)), 0.3, 0.7, 0.0, 200.0, 0.0, 0.0, 1.0), True))
+        outer = o.Group()
+        outer.add_child(g)
+        return o.World([outer], [o.PointLight(o.point(-10, 10, -10), o.Color.white())])
+    lo = np.array([0.3 - 1.3, -0.2 - 0.7, 0.1 - 0.9])
+    hi = np.array([0.3 + 1.3, -0.2 + 0.7, 0.1 + 0.9])
+    rng = np.random.default_rng(5)
+    origins, dirs = [], []
+    for _ in range(3000):
+        p = np.where(rng.random(3) < 0.5, lo, hi).astype(np.float64)
+        free = rng.integers(0, 4)          # 3: a corner; else a point on the edge along that axis
+        if free < 3:
+            p[free] = rng.uniform(lo[free], hi[free])
+        d = rng.uniform(0.2, 1.0, 3) * rng.choice([-1.0, 1.0], 3)
+        d /= np.linalg.norm(d)
+        o = p - rng.uniform(1.0, 5.0) * d
+        o = np.nextafter(o, o + rng.choice([-1.0, 0.0, 1.0], 3))  # straddle the tie by an ulp
+        origins.append(o)
+        dirs.append(d)
+    o, d = np.array(origins), np.array(dirs)
+    got = host.color_at(world(host), o, d, remaining=1)
+    ref = orc.color_at_batch(world(orc), o, d, remaining=1)
+    assert np.array_equal(got != 0, ref != 0)   # the same rays hit
+    assert np.abs(got - ref).max() <= 1e-11
+    assert 0.02 < (ref != 0).any(axis=1).mean() < 0.98
