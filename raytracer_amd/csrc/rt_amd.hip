@@ -906,13 +906,14 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
     return acc;
 }
 
-// Wavefronts per SIMD the register allocation aims for: scenes with transformed groups carry a
-// second copy of the ray and get one fewer.
+// Wavefronts per SIMD the register allocation aims for.  Four (128 VGPRs) is the most that fits
+// every variant without spilling; at five (96 VGPRs) a few spills land in the traversal loops
+// whenever the code around them changes, which costs more than the fifth wavefront hides.
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 5
+#define RT_MIN_WAVES 4
 #endif
 #ifndef RT_MIN_WAVES_XF
-#define RT_MIN_WAVES_XF 5
+#define RT_MIN_WAVES_XF 4
 #endif
 #ifndef RT_BLOCK_WAVES
 #define RT_BLOCK_WAVES 1  // wavefronts (8x8 tiles) per workgroup; one gives the dispatcher the finest grain
@@ -1212,21 +1213,44 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #endif
 
         // ---- per light: World::is_shadowed + Phong::lighting (world.rs:304-326, phong.rs:59-116)
+        // no_direct: the material has neither a diffuse nor a specular term and the colour is
+        // bounded, so both terms are exact zeros whatever the light does (0 * inf and 0 * NaN
+        // would not be).  Read through a pointer the compiler cannot match with the later loads,
+        // so that the coefficients are not kept in registers across the shadow traces.
+        bool no_direct = false;
+        if (shade) {
+            const RT_CONST SRec* q = sr;
+            asm volatile("" : "+v"(q));
+            no_direct = q->kd == 0.0 && q->ks == 0.0 && fabs(colour.x) < 1e100 && fabs(colour.y) < 1e100 &&
+                        fabs(colour.z) < 1e100;
+        }
         V3 acc = mk(0.0, 0.0, 0.0);
         for (int l = 0; l < L; ++l) {
             V3 lpos = mk(S.lights[l].position[0], S.lights[l].position[1], S.lights[l].position[2]);
             V3 lv = lpos - over;
             double distance = magnitude(lv);
             V3 lightv = lv / distance;
+            // World::is_shadowed only chooses between `ambient` and `ambient + diffuse + specular`
+            // (phong.rs:79-115).  Where the two are the same colour the shadow ray is not traced
+            // (it still counts as a ray of the frame): the light is behind the surface, so diffuse
+            // and specular are black (phong.rs:90-93), or the material has no diffuse and no
+            // specular term, so both are zero.  A zero's sign cannot show: the sums the colour
+            // enters start from +0.
+            const double ldn_before = dot(lightv, normalv);
+            const double big = 1e100;
+            const bool light_bounded = fabs(S.lights[l].intensity[0]) < big && fabs(S.lights[l].intensity[1]) < big &&
+                                       fabs(S.lights[l].intensity[2]) < big;
+            const bool shadow_matters =
+                shade && !(ldn_before < 0.0) && !(no_direct && light_bounded && ldn_before == ldn_before);
             Hit sh;
 #ifdef RT_PROFILE
             unsigned long long ps = __builtin_amdgcn_s_memtime();
 #endif
-            trace<MODE_SHADOW, XF, CULL, CSGM>(S, shade, over, lightv, distance, sh);
+            trace<MODE_SHADOW, XF, CULL, CSGM>(S, shadow_matters, over, lightv, distance, sh);
 #ifdef RT_PROFILE
             prof_shadow += __builtin_amdgcn_s_memtime() - ps;
             prof_visits += sh.visits;
-            prof_traces += (__ballot(shade) != 0ull) ? 1 : 0;
+            prof_traces += (__ballot(shadow_matters) != 0ull) ? 1 : 0;
 #endif
             if (shade) {
                 ++n_shadow;
@@ -1238,7 +1262,11 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
                 V3 surf = ambient;
                 if (!in_shadow) {
                     V3 diffuse = mk(0.0, 0.0, 0.0), specular = diffuse;
-                    double ldn = dot(lightv, normalv);
+                    // the cosine is computed again rather than kept in registers across the trace
+                    // (the empty asm hides that it is the same value)
+                    double nx = normalv.x;
+                    asm volatile("" : "+v"(nx));
+                    const double ldn = (lightv.x * nx + lightv.y * normalv.y) + lightv.z * normalv.z;
                     if (!(ldn < 0.0)) {
                         diffuse = effective * sr->kd * ldn;
                         V3 rv = reflect(-lightv, normalv);

@@ -298,3 +298,32 @@ def test_rays_through_group_box_edges(host, orc):
     assert np.array_equal(got != 0, ref != 0)   # the same rays hit
     assert np.abs(got - ref).max() <= 1e-11
     assert 0.02 < (ref != 0).any(axis=1).mean() < 0.98
+
+
+def test_shadow_rays_skipped_only_when_they_cannot_matter(host, orc):
+    """The device does not trace a shadow ray when `ambient` and `ambient + diffuse + specular`
+    (phong.rs:79-115) are the same colour: light behind the surface, or no diffuse and specular
+    term.  With an infinite colour channel 0 * inf is NaN, the two differ, and the ray must be traced:
+    the floor below is lit NaN except in the sphere's shadow, where it is inf."""
+    def world(o):
+        M = o.Matrix
+        glow = o.Phong(o.Solid(o.Color(float("inf"), 0.5, 0.25)), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0)
+        plain = o.Phong(o.Solid(o.Color(0.2, 0.5, 0.25)), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0)
+        floor = o.Plane(M.identity(), glow, True)
+        slab = o.Plane(M.translation(0.0, -5.0, 0.0), plain, True)   # ambient only, bounded: never needs a shadow ray
+        ball = o.Sphere(M.translation(0.0, 1.5, 0.0), o.Phong.default(), True)
+        return o.World([floor, slab, ball], [o.PointLight(o.point(0, 10, 0), o.Color.white()),
+                                            o.PointLight(o.point(0, -20, 0), o.Color(0.5, 0.5, 0.5))])
+    W, H = 64, 48
+
+    def camera(api):
+        return api.Camera(H, W, 1.0, api.Matrix.view_transform(api.point(0, 4.0, -8), api.point(0, 0, 0),
+                                                                api.vector(0, 1, 0)))
+    img, st = host.render(world(host), camera(host), stats=True)
+    ref, counters = orc.render(world(orc), camera(orc), threads=4, counters=True)
+    assert np.array_equal(np.isnan(img), np.isnan(ref)) and np.isnan(ref).any()
+    assert np.array_equal(np.isinf(img), np.isinf(ref)) and np.isinf(ref).any()
+    ok = np.isfinite(ref)
+    assert np.abs(img[ok] - ref[ok]).max() <= 1e-11
+    # skipped rays still count: the totals are the reference's
+    assert st.rays_shadow == counters["rays_shadow"]
