@@ -298,14 +298,16 @@ DI long long total_key(double v) {
     b ^= (long long)((unsigned long long)(b >> 63) >> 1);
     return b;
 }
-template <bool TRACK>
+// CONTAINERS: only the times <= 0 are of interest (see MODE_CONTAINERS); otherwise only the nearest
+// positive time.
+template <bool CONTAINERS>
 DI void leaf_count(LeafAcc& a, double t) {
-    if (t > 0.0) {
-        if (!a.found || t < a.best) {
+    if (!CONTAINERS) {
+        if (t > 0.0 && (!a.found || t < a.best)) {
             a.best = t;
             a.found = true;
         }
-    } else if (TRACK && t <= 0.0) {
+    } else if (t <= 0.0) {
         a.par ^= 1;
         a.negmax = fmax(a.negmax, t);
     }
@@ -335,11 +337,15 @@ DI int wave_min(int v) {
     return v;
 }
 
-enum { MODE_CLOSEST = 0, MODE_CLOSEST_TRACK = 1, MODE_SHADOW = 2 };
+enum { MODE_CLOSEST = 0, MODE_CONTAINERS = 1, MODE_SHADOW = 2 };
 
 // World::intersect_world + Intersection::hit for all lanes of the wavefront at once
 // (world.rs:55-68, group.rs:133-154 and the leaf local_intersect functions).  Must be called from
 // wave-uniform control flow; lanes without a ray pass active = false.
+// MODE_CONTAINERS: the second pass for a ray whose nearest hit (already in `h`) is transparent: what
+// World::prepare_computations' container walk (world.rs:99-132) needs, i.e. for every leaf the
+// parity and the latest of its times <= 0.  Positive times are ignored, so everything whose box
+// lies wholly in front of the origin is skipped.
 // MODE_SHADOW: `limit` is the distance to the light; when every leaf casts a shadow a lane stops
 // at its first intersection in (0, limit) (any such intersection implies the nearest one is too).
 // XF: the scene has transformed groups or triangles (T_XFORM records); without them the ray never
@@ -347,10 +353,12 @@ enum { MODE_CLOSEST = 0, MODE_CLOSEST_TRACK = 1, MODE_SHADOW = 2 };
 // CULL: the scene has T_CULL records.  CSGM: it has CSG shapes.
 template <int MODE, bool XF, bool CULL, bool CSGM>
 DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
-    constexpr bool TRACK = MODE == MODE_CLOSEST_TRACK;
-    h.found = false;
-    h.t = 0.0;
-    h.node = -1;
+    constexpr bool TRACK = MODE == MODE_CONTAINERS;
+    if (!TRACK) {
+        h.found = false;
+        h.t = 0.0;
+        h.node = -1;
+    }
     h.par = 0;
     h.a_t = 0.0;
     h.b_t = 0.0;
@@ -400,12 +408,13 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     // Written as selects, not branches: the hit state then stays in place across the loop instead of
     // being copied around the join points of every leaf visit.
     auto commit_leaf = [&]() {
-        const bool better = acc.found && (!h.found || acc.best < h.t);
-        h.found = h.found || acc.found;
-        h.t = better ? acc.best : h.t;
-        h.node = better ? acc_node : h.node;
-        h.par = better ? acc.par : h.par;
-        if (TRACK) {
+        if (!TRACK) {
+            const bool better = acc.found && (!h.found || acc.best < h.t);
+            h.found = h.found || acc.found;
+            h.t = better ? acc.best : h.t;
+            h.node = better ? acc_node : h.node;
+        } else {
+            h.par = acc_node == h.node ? acc.par : h.par;  // parity of the hit leaf's own earlier times
             const bool odd = acc.par != 0;
             const bool first = odd && (h.a_id < 0 || acc.negmax >= h.a_t);
             const bool second = odd && !first && (h.b_id < 0 || acc.negmax >= h.b_t);
@@ -482,7 +491,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
                 if (!TRACK) keep = keep && !(tmax < 0.0);                     // only positive times count
                 if (MODE == MODE_SHADOW) keep = keep && !(tmin > limit);     // beyond the light
-                keep = keep && !(h.found && tmin > h.t);                     // behind the nearest hit so far
+                if (!TRACK) keep = keep && !(h.found && tmin > h.t);         // behind the nearest hit so far
+                if (TRACK) keep = keep && !(tmin > 0.0);                      // only times <= 0 count
             }
             keep = keep && act;
             if (act && !keep) skip_until = skip;
@@ -574,7 +584,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             if (!CSGM || csg_depth == 0) {  // inside a CSG shape its filter needs every intersection
                 if (!TRACK) inside = inside && !(tmax < -tpad);
                 if (MODE == MODE_SHADOW) inside = inside && !(tmin > limit + tpad);
-                inside = inside && !(h.found && tmin > h.t + tpad);
+                if (!TRACK) inside = inside && !(h.found && tmin > h.t + tpad);
+                if (TRACK) inside = inside && !(tmin > tpad);
             }
             if (act && !inside) skip_until = skip;
             const bool enter = __ballot(inside) != 0ull;
@@ -1049,7 +1060,13 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
         unsigned long long pt = __builtin_amdgcn_s_memtime();
 #endif
-        trace<TRACK ? MODE_CLOSEST_TRACK : MODE_CLOSEST, XF, CULL, CSGM>(S, pending, ro, rd, 0.0, h);
+        trace<MODE_CLOSEST, XF, CULL, CSGM>(S, pending, ro, rd, 0.0, h);
+        if (TRACK) {
+            // n1/n2 (world.rs:99-132) are only read when the hit material is transparent
+            // (world.rs:185, 243-246): only those lanes run the container pass.
+            const bool need = pending && h.found && S.shade[h.node].transp != 0.0;
+            if (__ballot(need) != 0ull) trace<MODE_CONTAINERS, XF, CULL, CSGM>(S, need, ro, rd, 0.0, h);
+        }
 #ifdef RT_PROFILE
         prof_closest += __builtin_amdgcn_s_memtime() - pt;
         prof_visits += h.visits;
