@@ -2,17 +2,22 @@
 // include/rt_abi.h.
 //
 // Execution model
-//   * one lane = one pixel (or one caller-supplied ray), one wavefront = one 8x8 pixel tile,
-//     256-thread workgroups (4 tiles side by side); no LDS, no barriers, no matrix cores: the path
-//     has no dense contraction, it is scalar f64 arithmetic per ray.
-//   * scene traversal is wave-synchronous: the wavefront walks the pre-order node array with ONE
-//     uniform node index.  Node records, matrices, boxes and triangles are therefore fetched with
-//     scalar loads (constant address space) into SGPRs and cost no vector registers or vector
-//     memory traffic.  Each lane only keeps the index up to which it is masked off (`skip_until`),
-//     set when its ray misses a group's bounding box; when a wave-wide ballot shows that no lane
-//     is inside a group the whole subtree is skipped with the node's skip link.
+//   * one lane = one pixel (or one caller-supplied ray), one wavefront = one 8x8 pixel tile, one
+//     wavefront per workgroup; no barriers, no matrix cores: the path has no dense contraction, it
+//     is scalar f64 arithmetic per ray.  LDS only holds finished pixels until the tile is stored.
+//   * scene traversal is wave-synchronous: the wavefront walks an array of 128-byte traversal
+//     records (TRec, the node table in pre-order) with ONE uniform index.  Records are therefore
+//     fetched with scalar loads (constant address space) into SGPRs and cost no vector registers or
+//     vector memory traffic.  Each lane only keeps the index up to which it is masked off
+//     (`skip_until`), set when its ray misses a group's bounding box; when a wave-wide ballot
+//     shows that no lane is inside a group the whole subtree is skipped with the skip link.
+//   * what cannot change the result is not computed: leaves behind padded boxes the ray misses,
+//     subtrees whose box times cannot count, shadow rays whose outcome the colour does not depend
+//     on, the container bookkeeping for hits that are not transparent.
 //   * recursion (reflection, refraction) is an explicit per-lane frame stack in scratch memory;
 //     results are combined in the reference's summation order so colours are bit-identical.
+//   * tiles are rendered expensive ones first (tile_class_kernel), so the frame does not end on
+//     a few long wavefronts.
 //
 // Arithmetic contract: IEEE f64, reference operation order, no FMA contraction (the file is
 // compiled with -ffp-contract=off and carries the pragma below), correctly rounded / and sqrt.
@@ -51,9 +56,9 @@ namespace {
 // A finite sphere, cube or cylinder leaf is preceded by a T_CULL record: a padded box
 // around the leaf in the space its ray arrives in.  Lanes whose ray cannot reach the box skip
 // the leaf; this never changes a result, it only avoids arithmetic whose outcome is "no hit".
-// A CSG shape (csg.rs) is bracketed by T_CSG_BEGIN (its box; `node` = index of the matching end
-// record) and T_CSG_END (`node` = the CSG node, `skip` = first node after its left operand, the
-// operation in bits 12-13).  Between them the leaves collect their intersections per lane instead
+// A CSG shape (csg.rs) is bracketed by T_CSG_BEGIN (its box, tested like a group's; `skip` = the
+// record after the matching end record) and T_CSG_END (`node` = the CSG node, `skip` = the NODE
+// index where its right operand starts, the operation in bits 12-13).  Between them the leaves collect their intersections per lane instead
 // of competing for the nearest hit; the end record sorts and filters them.
 enum { T_XFORM = 8, T_CULL = 9, T_CSG_BEGIN = 10, T_CSG_END = 11, T_HAS_INV = 0x100, T_CLOSED = 0x200,
        T_OWN_XFORM = 0x400, T_CSG_OP_SHIFT = 12 };
@@ -90,21 +95,17 @@ struct DevScene {
     const RT_CONST SRec* shade;
     const RT_CONST TRec* trav;
     int n_trav;
-    const RT_CONST rt_node* nodes;
-    const RT_CONST rt_xform* xforms;
-    const RT_CONST rt_aabb* aabbs;
-    const RT_CONST rt_range* ranges;
+    const RT_CONST rt_xform* xforms;  // ancestors' transforms for shading (SRec::anc_xf)
     const RT_CONST rt_tri* tris;
     const RT_CONST rt_tri_normals* trin;
-    const RT_CONST rt_material* mats;
     const RT_CONST rt_pattern* pats;
     const RT_CONST double* patx;
     const RT_CONST rt_light* lights;
-    int n_nodes;
     int n_lights;
     int all_cast_shadow;
     int finite_bounds;  // every group box is finite (no plane inside a group)
     double prune_base;  // 1 + the largest |coordinate| of any group box; infinite when a box is
+                        // (scales the margin for pruning subtrees by their box times)
 };
 
 struct DevJob {
@@ -115,7 +116,6 @@ struct DevJob {
     // partition
     int rank, world_size, tiles_x, local_tile_rows;
     int max_depth;
-    int xcd_remap;
     int wide_stores;  // f64 output: base 16-byte aligned and even width; u8 output: base 4-byte aligned and width % 4 == 0
     int out_u8;       // the output is 3 bytes per pixel, quantised like Canvas::clamp, instead of 3 doubles
     const int* tile_order;  // three arrays of tiles_x * local_tile_rows tile indices, one per cost class, or null
@@ -987,15 +987,12 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
 }
 
 // Pixel of this lane: column, row within this rank's compact buffer, and local tile row.
-// Workgroups are dealt round-robin to the 8 XCDs; the optional remap gives each XCD a contiguous
-// band of tiles.  Cheap enough to evaluate twice instead of holding the result in registers.
+// Workgroups are dealt round-robin to the 8 XCDs, so consecutive tiles land on different XCDs and an
+// expensive region of the frame is spread over all of them (giving each XCD a contiguous band of
+// tiles instead puts the default scene's glass sphere on one XCD and costs 60 % more time).
+// Cheap enough to evaluate twice instead of holding the result in registers.
 DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, int& lty) {
-    const unsigned nwg = gridDim.x;
-    unsigned b = blockIdx.x;
-    if (J.xcd_remap) {
-        unsigned q = nwg / 8, r = nwg % 8, xcd = b % 8, idx = b / 8;
-        b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    const unsigned b = blockIdx.x;
     long long tile = (long long)b * RT_BLOCK_WAVES + wave;
     const long long n_tiles = (long long)J.tiles_x * J.local_tile_rows;
     if (J.tile_order && tile < n_tiles) {
@@ -1447,7 +1444,8 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
     }
 }
 
-// Device self-test of div_by: out_fast[i] = div_by(a[i], d[i], 1.0 / d[i]), out_ieee[i] = a[i] / d[i].
+// Device self-test of rcp_exact and div_by: out_fast[i] = div_by(a[i], d[i], rcp_exact(d[i])), or NaN when
+// rcp_exact(d[i]) != 1.0 / d[i]; out_ieee[i] = a[i] / d[i].
 __global__ void division_selftest_kernel(long long n, const double* a, const double* d, double* out_fast,
                                          double* out_ieee) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2017,18 +2015,13 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             else if ((r.kind & 0xff) == T_CULL) s->any_cull = true;
             else if ((r.kind & 0xff) == T_CSG_BEGIN) s->any_csg = true;
     }
-    if ((rc = upload(s, d->nodes, d->n_nodes, &s->dev.nodes)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->xforms, d->n_xforms, &s->dev.xforms)) != RT_OK) return cleanup(rc);
-    if ((rc = upload(s, d->aabbs, d->n_aabbs, &s->dev.aabbs)) != RT_OK) return cleanup(rc);
-    if ((rc = upload(s, d->ranges, d->n_ranges, &s->dev.ranges)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->tris, d->n_tris, &s->dev.tris)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->tri_normals, d->n_tris, &s->dev.trin)) != RT_OK) return cleanup(rc);
-    if ((rc = upload(s, d->materials, d->n_materials, &s->dev.mats)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->patterns, d->n_patterns, &s->dev.pats)) != RT_OK) return cleanup(rc);
     if ((rc = upload(s, d->pattern_xforms, (size_t)d->n_pattern_xforms * 12, &s->dev.patx)) != RT_OK)
         return cleanup(rc);
     if ((rc = upload(s, d->lights, d->n_lights, &s->dev.lights)) != RT_OK) return cleanup(rc);
-    s->dev.n_nodes = d->n_nodes;
     s->dev.n_lights = d->n_lights;
     s->dev.all_cast_shadow = all_cast ? 1 : 0;
     s->dev.finite_bounds = 1;
@@ -2107,10 +2100,6 @@ static int render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm
     job.tiles_x = (cam->width + RT_TILE - 1) / RT_TILE;
     job.local_tile_rows = local_tile_rows(cam->height, prm);
     job.max_depth = prm->max_depth;
-    {
-        const char* e = getenv("RT_XCD_REMAP");
-        job.xcd_remap = e ? atoi(e) : 0;
-    }
     job.n_rays = 0;
     job.out_u8 = out_u8 ? 1 : 0;
     if (out_u8)

@@ -134,3 +134,61 @@ def test_render_without_gpu_fails_loudly(host):
     with pytest.raises(abi.RtError) as e:
         host.render(world, cam)
     assert e.value.code == abi.RT_ERR_NO_DEVICE
+
+
+def test_csg_nodes_flatten_and_validate(host):
+    """An RT_CSG node carries its operation in the flags, has exactly two operands laid out like a
+    group's children, and the limits on nesting and on intersections per ray are checked when the
+    scene is created (no device needed to get that far)."""
+    lib = host.abi
+    M = host.Matrix
+    left = host.Sphere(M.identity(), host.Phong.default(), True)
+    g = host.Group(M.translation(1, 0, 0))
+    g.add_child(host.Cube(M.identity(), host.Phong.default(), True))
+    g.add_child(host.Cylinder(M.identity(), host.Phong.default(), True, -1.0, 1.0, True))
+    csg = host.CSG(host.DIFFERENCE, left, g, M.scaling(2, 2, 2))
+    world = host.World([csg], [host.PointLight(host.point(0, 10, 0), host.Color.white())])
+    nodes = host.flat_nodes(world)
+    assert [n.type for n in nodes] == [8, 1, 0, 3, 4]                  # csg, sphere, group, cube, cylinder
+    assert (nodes[0].flags >> 4) & 3 == host.DIFFERENCE and not nodes[0].flags & 1   # casts_shadow is false
+    assert nodes[0].skip == 5 and nodes[1].skip == 2 and nodes[2].skip == 5
+    assert [n.parent for n in nodes] == [-1, 0, 0, 2, 2]
+    assert [n.ctx for n in nodes] == [-1, 0, 0, 2, 2]                  # the CSG's transform, then the group's
+    assert nodes[0].material == -1 and nodes[0].data >= 0
+
+    desc = host.scene_desc(world)
+    handle = C.c_void_p()
+
+    def create(d):
+        rc = lib.rt_scene_create(C.byref(d), 0, C.byref(handle))
+        if handle:
+            lib.rt_scene_destroy(handle)
+            handle.value = None
+        return rc
+
+    assert create(desc) in (abi.RT_OK, abi.RT_ERR_NO_DEVICE)
+    arr = (abi.rt_node * desc.n_nodes)(*[desc.nodes[i] for i in range(desc.n_nodes)])
+    broken = abi.rt_scene_desc.from_buffer_copy(desc)
+    broken.nodes = arr
+    arr[1].skip = 5                       # the left operand swallows the right one
+    assert create(broken) == abi.RT_ERR_INVALID
+    arr[1].skip = 2
+    arr[2].parent = 1                     # right operand not a child of the CSG shape
+    assert create(broken) == abi.RT_ERR_INVALID
+    arr[2].parent = 0
+    assert create(broken) in (abi.RT_OK, abi.RT_ERR_NO_DEVICE)
+
+    def chain(n):
+        shape = host.Sphere(M.identity(), host.Phong.default(), True)
+        for k in range(n):
+            shape = host.CSG(host.UNION, shape, host.Sphere(M.translation(0.1 * (k + 1), 0, 0), host.Phong.default(), True))
+        return shape
+    ok = host.scene_desc(host.World([chain(4)], []))
+    assert create(ok) in (abi.RT_OK, abi.RT_ERR_NO_DEVICE)
+    deep = host.scene_desc(host.World([chain(5)], []))
+    assert create(deep) == abi.RT_ERR_LIMIT and b"nested" in lib.rt_last_error()
+    wide = host.Group()
+    for k in range(13):
+        wide.add_child(host.Sphere(M.translation(0.1 * k, 0, 0), host.Phong.default(), True))
+    many = host.scene_desc(host.World([host.CSG(host.UNION, wide, host.Sphere(M.identity(), host.Phong.default(), True))], []))
+    assert create(many) == abi.RT_ERR_LIMIT and b"intersections" in lib.rt_last_error()
