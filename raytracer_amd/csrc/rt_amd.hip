@@ -1660,14 +1660,38 @@ bool affine_forward(const double inv[12], double fwd[12]) {
     return true;
 }
 
+// Fills a T_CULL record for the box [bmin, bmax]; smin / smax are the smallest / largest stretch of
+// the leaf's object-to-parent map (1 for untransformed triangles).
+bool fill_cull(const double bmin[3], const double bmax[3], double smin, double smax, TRec& out) {
+    double size = 0.0, reach = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        size = std::fmax(size, bmax[k] - bmin[k]);
+        reach = std::fmax(reach, std::fmax(std::fabs(bmin[k]), std::fabs(bmax[k])));
+    }
+    if (!std::isfinite(size) || !std::isfinite(reach) || !(smin > 0.0) || !std::isfinite(smax)) return false;
+    // A ray origin at distance D is at most D / smin from the leaf in object space, where the
+    // quadratic's discriminant carries an error of about 10 eps (D / smin)^2; a line that misses
+    // the unit shape by less than half of that can still be reported as a hit, which is up to
+    // smax times as far in this space.  10^-9 leaves six orders of magnitude over eps.  (The
+    // triangle test has no such cancellation; the same padding is simply generous for it.)
+    const double far_term = 1e-9 * smax / (smin * smin);
+    out.kind = T_CULL;
+    out.r0 = 1e-6 * (size + reach) + 2.0 * far_term * reach * reach;  // |o - c|^2 <= 2 |o|^2 + 2 reach^2
+    out.r1 = 2.0 * far_term;
+    if (!std::isfinite(out.r0) || !std::isfinite(out.r1)) return false;
+    for (int k = 0; k < 3; ++k) {
+        out.p[k] = bmin[k];
+        out.p[3 + k] = bmax[k];
+    }
+    return true;
+}
+
 // The T_CULL record of a finite sphere, cube or cylinder leaf, or false when the leaf is unbounded
 // (open-ended cylinders) or its transform is too degenerate to bound.
 bool cull_record(const rt_scene_desc* d, const rt_node& n, TRec& out) {
     // Cones are left out: for a ray parallel to one half of the cone the reference reports the
     // single wall intersection without the minimum < y < maximum check (cone.rs:119-127), so a
     // truncated cone can be hit outside any box around it.
-    static const bool disabled = getenv("RT_NO_CULL") && atoi(getenv("RT_NO_CULL")) != 0;
-    if (disabled) return false;
     double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};
     if (n.type == RT_CYLINDER) {
         const double mn = d->ranges[n.data].minimum, mx = d->ranges[n.data].maximum;
@@ -1688,65 +1712,66 @@ bool cull_record(const rt_scene_desc* d, const rt_node& n, TRec& out) {
             bmax[row] = std::fmax(bmax[row], v);
         }
     }
-    double size = 0.0, reach = 0.0, smin = INFINITY, smax = 0.0;
+    double smin = INFINITY, smax = 0.0;
     for (int k = 0; k < 3; ++k) {
-        size = std::fmax(size, bmax[k] - bmin[k]);
-        reach = std::fmax(reach, std::fmax(std::fabs(bmin[k]), std::fabs(bmax[k])));
         const double col = std::sqrt(fwd[k] * fwd[k] + fwd[4 + k] * fwd[4 + k] + fwd[8 + k] * fwd[8 + k]);
         smin = std::fmin(smin, col);
         smax = std::fmax(smax, col);
     }
-    if (!std::isfinite(size) || !std::isfinite(reach) || !(smin > 0.0)) return false;
-    // A ray origin at distance D is at most D / smin from the leaf in object space, where the
-    // quadratic's discriminant carries an error of about 10 eps (D / smin)^2; a line that misses
-    // the unit shape by less than half of that can still be reported as a hit, which is up to
-    // smax times as far in this space.  10^-9 leaves six orders of magnitude over eps.
-    const double far_term = 1e-9 * smax / (smin * smin);
-    out.kind = T_CULL;
-    out.r0 = 1e-6 * (size + reach) + 2.0 * far_term * reach * reach;  // |o - c|^2 <= 2 |o|^2 + 2 reach^2
-    out.r1 = 2.0 * far_term;
-    if (!std::isfinite(out.r0) || !std::isfinite(out.r1)) return false;
-    for (int k = 0; k < 3; ++k) {
-        out.p[k] = bmin[k];
-        out.p[3 + k] = bmax[k];
+    return fill_cull(bmin, bmax, smin, smax, out);
+}
+
+// One T_CULL record in front of a run of sibling triangles [lo, hi) that have no transform of their
+// own: the box around all of them, in their parent's space.  Long runs come from Group::divide
+// (group.rs:79-105), which leaves every triangle that straddles a split plane in the parent.
+bool cluster_cull_record(const rt_scene_desc* d, int lo, int hi, TRec& out) {
+    double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int i = lo; i < hi; ++i) {
+        const rt_tri& t = d->tris[d->nodes[i].data];
+        for (int k = 0; k < 3; ++k) {
+            const double a = t.p1[k], b = t.p1[k] + t.e1[k], c = t.p1[k] + t.e2[k];  // p1, p2, p3 up to an ulp
+            bmin[k] = std::fmin(bmin[k], std::fmin(a, std::fmin(b, c)));
+            bmax[k] = std::fmax(bmax[k], std::fmax(a, std::fmax(b, c)));
+        }
     }
-    return true;
+    return fill_cull(bmin, bmax, 1.0, 1.0, out);
 }
 
 // Lays the node table out as traversal records (see TRec).
 std::vector<TRec> build_records(const rt_scene_desc* d) {
     const int N = d->n_nodes;
+    static const bool no_cull = getenv("RT_NO_CULL") && atoi(getenv("RT_NO_CULL")) != 0;
     std::vector<TRec> out;
+    // Skip links are node indices while the records are being emitted and are turned into record
+    // indices at the end, when pre[] is known:  record skip = pre[skip_node] + skip_extra.
+    //   pre[k]: index of the first record emitted on reaching node k (before the end records of
+    //           the CSG shapes that close at k); rec[k]: first record of node k itself.
     // A CSG shape's end record follows its last descendant.  Several shapes can end at the same
     // node index k (each the last child of the one before); their end records come innermost
     // first.  A skip over node X must land after the end records of the CSG shapes inside X (or X
-    // itself) and before those of the shapes around X:
-    //   target(X) = pre[X.skip] + ends_inside[X]
-    // pre[k]: record index before the end records that close at k; rec[k]: first record of node k.
-    std::vector<int> last_child(N, -1), ends_inside(N, 0), closes(N + 1, 0), pre(N + 1, 0), rec(N + 1, 0);
+    // itself) and before those of the shapes around X: skip_extra = ends_inside[X].
+    std::vector<int> last_child(N, -1), ends_inside(N, 0), pre(N + 1, -1), rec(N + 1, -1);
+    std::vector<int> skip_node, skip_extra;  // per record; skip_node < 0: the record's skip field is final
     for (int c = 0; c < N; ++c) {
         const int p = d->nodes[c].parent;
         if (p >= 0 && d->nodes[c].skip == d->nodes[p].skip) last_child[p] = c;
-        if (d->nodes[c].type == RT_CSG) ++closes[d->nodes[c].skip];
     }
     for (int x = N - 1; x >= 0; --x)
         ends_inside[x] = (d->nodes[x].type == RT_CSG ? 1 : 0) + (last_child[x] >= 0 ? ends_inside[last_child[x]] : 0);
+    auto push = [&](const TRec& r, int node_skip, int extra) {
+        out.push_back(r);
+        skip_node.push_back(node_skip);
+        skip_extra.push_back(extra);
+    };
     auto own_payload = [&](const rt_node& n) {
         return n.type == RT_GROUP || n.type == RT_CSG || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
     };
-    int count = 0;
-    for (int i = 0; i < N; ++i) {
+    auto plain_triangle = [&](int i) {
         const rt_node& n = d->nodes[i];
-        pre[i] = count;
-        count += closes[i];
-        rec[i] = count;
-        TRec probe{};
-        count += ((n.xform >= 0 && own_payload(n)) || cull_record(d, n, probe)) ? 2 : 1;
-    }
-    pre[N] = count;
-    count += closes[N];
-    rec[N] = count;
-    out.reserve(count);
+        return (n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE) && n.xform < 0;
+    };
+    auto ctx_record = [&](const rt_node& n) { return n.ctx >= 0 ? rec[n.ctx] : -1; };  // ancestors are already emitted
+
     std::vector<int> open;  // CSG shapes whose end record is still to come
     auto close_until = [&](int k) {
         while (!open.empty() && d->nodes[open.back()].skip == k) {
@@ -1756,31 +1781,30 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
             TRec e{};
             e.kind = T_CSG_END | (((n.flags & RT_NODE_CSG_OP_MASK) >> 4) << T_CSG_OP_SHIFT);
             e.node = c;
-            e.skip = d->nodes[c + 1].skip;  // node index where the right operand starts
-            e.ctx = n.xform >= 0 ? rec[c] : (n.ctx >= 0 ? rec[n.ctx] : -1);
-            out.push_back(e);
+            e.skip = d->nodes[c + 1].skip;  // NODE index where the right operand starts
+            e.ctx = n.xform >= 0 ? rec[c] : ctx_record(n);
+            push(e, -1, 0);
         }
     };
-    for (int i = 0; i < N; ++i) {
-        close_until(i);
+    auto emit_node = [&](int i) {
         const rt_node& n = d->nodes[i];
         TRec r{};
-        r.skip = pre[n.skip] + ends_inside[i];
-        r.ctx = n.ctx >= 0 ? rec[n.ctx] : -1;
+        r.ctx = ctx_record(n);
         r.node = i;
         int flags = (n.flags & RT_NODE_CLOSED) ? T_CLOSED : 0;
+        rec[i] = (int)out.size();
         if (n.xform >= 0 && own_payload(n)) {
             TRec x = r;
             x.kind = T_XFORM | T_HAS_INV;
             std::memcpy(x.p, d->xforms[n.xform].inv, sizeof x.p);
-            out.push_back(x);
+            push(x, n.skip, ends_inside[i]);
             flags |= T_OWN_XFORM;
             r.ctx = rec[i];  // the node itself is tested in its own space
         } else {
             TRec c = r;
-            if (cull_record(d, n, c)) {
-                c.skip = rec[i] + 2;  // past the leaf
-                out.push_back(c);
+            if (!no_cull && cull_record(d, n, c)) {
+                c.skip = (int)out.size() + 2;  // past the leaf
+                push(c, -1, 0);
             }
             if (n.xform >= 0) {
                 flags |= T_HAS_INV;
@@ -1800,9 +1824,47 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
             std::memcpy(r.p + 3, d->tris[n.data].e1, 3 * sizeof(double));
             std::memcpy(r.p + 6, d->tris[n.data].e2, 3 * sizeof(double));
         }
-        out.push_back(r);
+        push(r, n.skip, ends_inside[i]);
+    };
+    // A run [lo, hi) of sibling triangles gets a box, and so do its halves while they hold at least
+    // CLUSTER_MIN triangles: a wavefront whose rays all miss a box skips that part of the run.  The
+    // order of the leaves (which breaks ties between equal times) is untouched.
+    constexpr int CLUSTER_MIN = 4;
+    auto emit_run = [&](auto&& self, int lo, int hi) -> void {
+        if (pre[lo] < 0) pre[lo] = (int)out.size();
+        TRec c{};
+        if (hi - lo >= CLUSTER_MIN && cluster_cull_record(d, lo, hi, c)) {
+            c.ctx = ctx_record(d->nodes[lo]);
+            c.node = lo;
+            push(c, hi, 0);  // to the first record emitted for node hi
+            const int mid = lo + (hi - lo) / 2;
+            self(self, lo, mid);
+            self(self, mid, hi);
+            return;
+        }
+        for (int i = lo; i < hi; ++i) {
+            if (pre[i] < 0) pre[i] = (int)out.size();
+            emit_node(i);
+        }
+    };
+    for (int i = 0; i < N;) {
+        pre[i] = (int)out.size();
+        close_until(i);
+        int j = i;
+        if (!no_cull && plain_triangle(i))
+            while (j < N && plain_triangle(j) && d->nodes[j].parent == d->nodes[i].parent) ++j;
+        if (j - i >= CLUSTER_MIN) {
+            emit_run(emit_run, i, j);
+            i = j;
+        } else {
+            emit_node(i);
+            ++i;
+        }
     }
+    pre[N] = (int)out.size();
     close_until(N);
+    for (size_t r = 0; r < out.size(); ++r)
+        if (skip_node[r] >= 0) out[r].skip = pre[skip_node[r]] + skip_extra[r];
     return out;
 }
 

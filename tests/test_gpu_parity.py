@@ -38,6 +38,8 @@ def check(img, ref, tol=1e-11):
     ("teapot", (96, 96)),
     ("smooth_teapot", (96, 96)),
     ("csg", (200, 120)),
+    ("dragon", (160, 96)),
+    ("teapot", (240, 160)),
 ])
 def test_render_matches_oracle(host, orc, name, size):
     W, H = size
