@@ -1829,7 +1829,7 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
     // A run [lo, hi) of sibling triangles gets a box, and so do its halves while they hold at least
     // CLUSTER_MIN triangles: a wavefront whose rays all miss a box skips that part of the run.  The
     // order of the leaves (which breaks ties between equal times) is untouched.
-    constexpr int CLUSTER_MIN = 4;
+    constexpr int CLUSTER_MIN = 2;  // measured on the dragon mesh: 2 beats 3, 4, 6, 8 (0.84 / 0.87 / 0.94 / 1.04 / 1.12 ms)
     auto emit_run = [&](auto&& self, int lo, int hi) -> void {
         if (pre[lo] < 0) pre[lo] = (int)out.size();
         TRec c{};
