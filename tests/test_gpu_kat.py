@@ -232,11 +232,52 @@ def quadric_world(api, seed):
     return api.World(objects, lights)
 
 
+def triangle_fan_group(api, rng):
+    """A small closed mesh (an octahedron subdivided once: 32 triangles) in a transformed group,
+    divided like the OBJ meshes are, so that sibling runs get cluster boxes and groups get pruned."""
+    M = api.Matrix
+    verts = [np.array(v, dtype=np.float64) for v in ((1, 0, 0), (-1, 0, 0), (0, 1, 0), (0, -1, 0), (0, 0, 1), (0, 0, -1))]
+    faces = [(0, 2, 4), (2, 1, 4), (1, 3, 4), (3, 0, 4), (2, 0, 5), (1, 2, 5), (3, 1, 5), (0, 3, 5)]
+    tris = []
+    for a, b, c in faces:
+        pa, pb, pc = verts[a], verts[b], verts[c]
+        mab, mbc, mca = [(x + y) / np.linalg.norm(x + y) for x, y in ((pa, pb), (pb, pc), (pc, pa))]
+        tris += [(pa, mab, mca), (mab, pb, mbc), (mca, mbc, pc), (mab, mbc, mca)]
+    mat = api.Phong(api.Solid(api.Color(*rng.uniform(0, 1, 3))), 0.2, 0.7, 0.3, 50.0, 0.3, 0.0, 1.0)
+    g = api.Group(M.translation(*rng.uniform(-3, 3, 3)) * M.rotation_y(rng.uniform(-3, 3)) * M.scaling(*rng.uniform(0.5, 2.0, 3)))
+    for k, (p1, p2, p3) in enumerate(tris):
+        pts = [api.point(*p) for p in (p1, p2, p3)]
+        if k % 2:
+            g.add_child(api.SmoothTriangle(*pts, *[api.vector(*p) for p in (p1, p2, p3)], None, mat, True))
+        else:
+            g.add_child(api.Triangle(*pts, None, mat, True))
+    g.divide(1)
+    return g
+
+
+def grouped_world(api, seed):
+    """quadric_world's objects inside nested, transformed, divided groups, plus a triangle mesh."""
+    flat = quadric_world(api, seed)
+    rng = np.random.default_rng(2000 + seed)
+    M = api.Matrix
+    outer = api.Group(M.rotation_z(rng.uniform(-0.5, 0.5)))
+    inner = api.Group(M.translation(*rng.uniform(-1, 1, 3)) * M.scaling(*rng.uniform(0.7, 1.4, 3)))
+    for k, obj in enumerate(flat.objects):
+        (inner if k % 2 else outer).add_child(obj)
+    outer.add_child(inner)
+    outer.add_child(triangle_fan_group(api, rng))
+    outer.divide(1)
+    return api.World([outer], flat.lights)
+
+
+@pytest.mark.parametrize("grouped", [False, True])
 @pytest.mark.parametrize("seed", list(range(8)))
-def test_culling_is_conservative(host, orc, seed):
+def test_culling_is_conservative(host, orc, seed, grouped):
     """Rays from 10 to 10^7 units away aimed at and just past the silhouettes of the objects: the
-    padded boxes must keep every ray the exact arithmetic counts as a hit, including the false hits
-    that cancellation produces for far origins."""
+    padded boxes (single leaves, runs of triangles) and the pruning of groups by their box times
+    must keep every ray the exact arithmetic counts as a hit, including the false hits that
+    cancellation produces for far origins."""
+    make = grouped_world if grouped else quadric_world
     rng = np.random.default_rng(seed)
     origins, dirs = [], []
     for dist in (10.0, 1e3, 1e5, 1e7):
@@ -253,8 +294,8 @@ def test_culling_is_conservative(host, orc, seed):
             dirs.append(d / np.linalg.norm(d))
     o = np.array(origins)
     d = np.array(dirs)
-    got = host.color_at(quadric_world(host, seed), o, d, remaining=3)
-    ref = orc.color_at_batch(quadric_world(orc, seed), o, d, remaining=3)
+    got = host.color_at(make(host, seed), o, d, remaining=3)
+    ref = orc.color_at_batch(make(orc, seed), o, d, remaining=3)
     finite = np.isfinite(ref)
     assert np.array_equal(np.isfinite(got), finite)
     err = np.abs(got[finite] - ref[finite]) / np.maximum(1.0, np.abs(ref[finite]))
