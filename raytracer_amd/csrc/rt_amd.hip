@@ -1829,6 +1829,43 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
     // A run [lo, hi) of sibling triangles gets a box, and so do its halves while they hold at least
     // CLUSTER_MIN triangles: a wavefront whose rays all miss a box skips that part of the run.  The
     // order of the leaves (which breaks ties between equal times) is untouched.
+    // The run is cut where the two parts' boxes are cheapest to visit (surface area times count,
+    // the usual estimate of how many rays reach a box), keeping the order of the leaves.
+    auto tri_box = [&](int i, double mn[3], double mx[3]) {
+        const rt_tri& t = d->tris[d->nodes[i].data];
+        for (int k = 0; k < 3; ++k) {
+            const double a = t.p1[k], b = t.p1[k] + t.e1[k], c = t.p1[k] + t.e2[k];
+            mn[k] = std::fmin(mn[k], std::fmin(a, std::fmin(b, c)));
+            mx[k] = std::fmax(mx[k], std::fmax(a, std::fmax(b, c)));
+        }
+    };
+    auto area = [](const double mn[3], const double mx[3]) {
+        const double x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+        return x * y + y * z + z * x;
+    };
+    std::vector<double> suffix_area;
+    auto best_split = [&](int lo, int hi) {
+        const int n = hi - lo;
+        if (n <= 2) return lo + n / 2;
+        suffix_area.assign(n + 1, 0.0);
+        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = n - 1; k >= 1; --k) {
+            tri_box(lo + k, mn, mx);
+            suffix_area[k] = area(mn, mx);
+        }
+        double pmn[3] = {INFINITY, INFINITY, INFINITY}, pmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int best = lo + n / 2;
+        double best_cost = INFINITY;
+        for (int k = 1; k < n; ++k) {
+            tri_box(lo + k - 1, pmn, pmx);
+            const double cost = area(pmn, pmx) * k + suffix_area[k] * (n - k);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = lo + k;
+            }
+        }
+        return best;
+    };
     constexpr int CLUSTER_MIN = 2;  // measured on the dragon mesh: 2 beats 3, 4, 6, 8 (0.84 / 0.87 / 0.94 / 1.04 / 1.12 ms)
     auto emit_run = [&](auto&& self, int lo, int hi) -> void {
         if (pre[lo] < 0) pre[lo] = (int)out.size();
@@ -1837,7 +1874,7 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
             c.ctx = ctx_record(d->nodes[lo]);
             c.node = lo;
             push(c, hi, 0);  // to the first record emitted for node hi
-            const int mid = lo + (hi - lo) / 2;
+            const int mid = best_split(lo, hi);
             self(self, lo, mid);
             self(self, mid, hi);
             return;
