@@ -232,6 +232,15 @@ def main():
                 "algorithmic_flops_per_launch": flops / world_size,
                 "oracle_rays_per_frame": work["rays"],
             }
+            # the secondary roof: the only streamed bytes are the frame itself (scene tables stay in cache)
+            frame_bytes = rows * W * 3 * (1 if u8 else 8)
+            traffic = out["roofline"]["traffic"]
+            out["roofline"]["hbm"] = {
+                "peak_gbs": HBM_PEAK_GBS,
+                "algorithmic_bytes_per_launch": frame_bytes,
+                "algorithmic_gbs": frame_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+                "measured_gbs": traffic / (kernel_ms * 1e-3) / 1e9 if traffic and kernel_ms > 0 else None,
+            }
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, W, H)
         print(json.dumps(out))
