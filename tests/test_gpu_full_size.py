@@ -70,3 +70,24 @@ def test_8k_frame_from_eight_ranks(host, orc):
     pos = {int(r): i for i, r in enumerate(half_rows)}
     idx = np.array([pos[int(r)] for r in rows])
     assert np.array_equal(half[idx], part)
+
+
+@pytest.mark.parametrize("name", ["glass", "csg", "smooth_teapot", "dragon"])
+def test_other_workloads_1920x1080(host, orc, name):
+    """The glass/pattern, CSG and mesh configurations at the size they are benchmarked at: a sample
+    of pixels against the oracle, and bytes = Canvas::clamp of the colours everywhere."""
+    W, H = 1920, 1080
+    mw, mc = scenes.WORKLOADS[name]
+    img, st = host.render(mw(host), mc(host, W, H), stats=True)
+    assert img.shape == (H, W, 3) and st.rays_primary == W * H
+    rng = np.random.default_rng(13)
+    n = 1500
+    xs, ys = rng.integers(0, W, n), rng.integers(0, H, n)
+    xs[: n // 2] = rng.integers(int(0.3 * W), int(0.7 * W), n // 2)   # where the objects are
+    ys[: n // 2] = rng.integers(int(0.3 * H), int(0.8 * H), n // 2)
+    ref = sampled_reference(orc, mw(orc), mc(orc, W, H), xs, ys)
+    got = img[ys, xs]
+    assert np.abs(got - ref).max() <= 1e-11
+    assert (quantise(got) != quantise(ref)).sum() == 0
+    img8 = host.render_u8(mw(host), mc(host, W, H))
+    assert np.array_equal(img8, quantise(img).astype(np.uint8))
