@@ -168,6 +168,17 @@ int rt_render_device_u8(rt_scene* scene, const rt_camera* camera, const rt_param
 /* Same, but synchronous into HOST memory; fills stats when not NULL. */
 int rt_render_u8(rt_scene* scene, const rt_camera* camera, const rt_params* params, uint8_t* rgb8_out,
                  rt_stats* stats);
+/* render followed by Canvas::to_ppm (src/canvas.rs:62-126), both on the device: the PPM text that
+ * main.rs writes to the output file (header, one image row per group of lines, lines broken
+ * before they reach 70 characters).  text_out is HOST memory of `capacity` bytes; *length gets the
+ * size of the text.  A frame needs at most 32 + height * (width * 12 + 1) bytes; when `capacity`
+ * is too small the call fails with RT_ERR_LIMIT and *length holds the size needed.  Whole frames
+ * only (world_size 1). */
+int rt_render_ppm(rt_scene* scene, const rt_camera* camera, const rt_params* params, char* text_out,
+                  uint64_t capacity, uint64_t* length, rt_stats* stats);
+/* Canvas::to_ppm alone, on `device`, for width * height * 3 clamped bytes in host memory. */
+int rt_ppm_encode(int device, const uint8_t* rgb8, int32_t width, int32_t height, char* text_out,
+                  uint64_t capacity, uint64_t* length);
 /* Replaces World::color_at (src/scene/world.rs:198-212) for n rays given as packed xyz origins
  * and directions in host memory; writes n*3 doubles to host memory. */
 int rt_color_at(rt_scene* scene, int64_t n, const double* origins, const double* directions,

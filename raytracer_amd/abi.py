@@ -100,6 +100,10 @@ SYMBOLS = {
                                       C.c_void_p]),
     "rt_render_u8": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(C.c_uint8),
                                C.POINTER(rt_stats)]),
+    "rt_render_ppm": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_char_p, C.c_uint64,
+                                C.POINTER(C.c_uint64), C.POINTER(rt_stats)]),
+    "rt_ppm_encode": (C.c_int, [C.c_int, C.POINTER(C.c_uint8), i32, i32, C.c_char_p, C.c_uint64,
+                                C.POINTER(C.c_uint64)]),
     "rt_color_at": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(c_d), C.POINTER(c_d), i32, C.POINTER(c_d),
                               C.POINTER(rt_stats)]),
     "rt_scene_launch_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),

@@ -114,6 +114,36 @@ class HostApi(Api):
                                          img.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(st)))
         return (img, st) if stats else img
 
+    def render_ppm(self, world, camera, max_depth=5, device=0, stats=False):
+        """render + Canvas::to_ppm (src/lib.rs:77-133, src/window/canvas.rs:62-126), both on the GPU
+        -> the bytes main.rs writes to the output file."""
+        prm = abi.rt_params(max_depth, 0, 1, 0)
+        cam = self.camera_block(camera)
+        scene = self.scene_handle(world, device)
+        cap = 32 + cam.height * (cam.width * 12 + 1)
+        buf = C.create_string_buffer(cap)
+        n = C.c_uint64()
+        st = abi.rt_stats()
+        rc = self.abi.rt_render_ppm(scene, C.byref(cam), C.byref(prm), buf, cap, C.byref(n), C.byref(st))
+        if rc != 0:
+            raise abi.RtError(rc, (self.abi.rt_last_error() or b"").decode())
+        text = buf.raw[:n.value]
+        return (text, st) if stats else text
+
+    def ppm_encode(self, img8, device=0, capacity=None):
+        """Canvas::to_ppm (src/window/canvas.rs:62-126) on the GPU for an (H, W, 3) uint8 image."""
+        img8 = np.ascontiguousarray(img8, dtype=np.uint8)
+        h, w = img8.shape[:2]
+        cap = 32 + h * (w * 12 + 1) if capacity is None else capacity
+        buf = C.create_string_buffer(max(cap, 1))
+        n = C.c_uint64()
+        rc = self.abi.rt_ppm_encode(device, img8.ctypes.data_as(C.POINTER(C.c_uint8)), w, h, buf, cap, C.byref(n))
+        if rc != 0:
+            err = abi.RtError(rc, (self.abi.rt_last_error() or b"").decode())
+            err.needed = n.value
+            raise err
+        return buf.raw[:n.value]
+
     def render_device(self, world, camera, d_ptr, stream=None, max_depth=5, device=0, rank=0, world_size=1,
                       u8=False):
         """Asynchronous render into device memory at address d_ptr (e.g. a torch tensor's data_ptr):

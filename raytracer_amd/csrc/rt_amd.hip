@@ -1444,6 +1444,68 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Canvas::to_ppm (src/window/canvas.rs:62-126) on the device, from clamped bytes.  The line breaking
+// is a sequential state machine per image row (a value goes on a new line when it would make the
+// line 70 characters or more, canvas.rs:96-126) and rows are independent, so one lane formats one
+// row: a first walk measures the row's text, a scan turns lengths into offsets, a second walk
+// writes the characters.  The walks are identical so that the offsets are exact.
+// ---------------------------------------------------------------------------------------------
+template <bool WRITE>
+DI unsigned ppm_row(const uint8_t* __restrict__ row, int n_values, char* __restrict__ dst) {
+    unsigned written = 0, line = 0;
+    auto put = [&](char c) {
+        if (WRITE) dst[written] = c;
+        ++written;
+    };
+    for (int i = 0; i < n_values; ++i) {
+        const unsigned v = row[i];
+        const unsigned digits = v >= 100u ? 3u : (v >= 10u ? 2u : 1u);
+        if (line + (digits + 1u) >= 70u) {
+            put('\n');
+            line = 0;
+        }
+        if (line > 0) {
+            put(' ');
+            ++line;
+        }
+        if (digits == 3u) put((char)('0' + v / 100u));
+        if (digits >= 2u) put((char)('0' + (v / 10u) % 10u));
+        put((char)('0' + v % 10u));
+        line += digits;
+        if (line + 1u == 70u) {
+            put('\n');
+            line = 0;
+        }
+    }
+    if (line > 0) put('\n');
+    return written;
+}
+__global__ void ppm_measure_kernel(const uint8_t* __restrict__ rgb8, int width, int height, unsigned long long* __restrict__ row_bytes) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y < height) row_bytes[y] = ppm_row<false>(rgb8 + (size_t)y * width * 3, width * 3, nullptr);
+}
+// row_bytes[y] becomes the offset of row y; row_bytes[height] the total.  A frame has a few thousand rows.
+__global__ void ppm_scan_kernel(int height, unsigned long long first, unsigned long long* __restrict__ row_bytes) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        unsigned long long at = first;
+        for (int y = 0; y < height; ++y) {
+            const unsigned long long n = row_bytes[y];
+            row_bytes[y] = at;
+            at += n;
+        }
+        row_bytes[height] = at;
+    }
+}
+__global__ void ppm_write_kernel(const uint8_t* __restrict__ rgb8, int width, int height,
+                                 const unsigned long long* __restrict__ row_offset, unsigned long long capacity,
+                                 char* __restrict__ text) {
+    const int y = blockIdx.x * blockDim.x + threadIdx.x;
+    if (y < height && row_offset[height] <= capacity)
+        ppm_row<true>(rgb8 + (size_t)y * width * 3, width * 3, text + row_offset[y]);
+}
+
 // Device self-test of rcp_exact and div_by: out_fast[i] = div_by(a[i], d[i], rcp_exact(d[i])), or NaN when
 // rcp_exact(d[i]) != 1.0 / d[i]; out_ieee[i] = a[i] / d[i].
 __global__ void division_selftest_kernel(long long n, const double* a, const double* d, double* out_fast,
@@ -2313,6 +2375,91 @@ int rt_selftest_division(int device, int64_t n, const double* a, const double* d
     }
     (void)hipFree(buf);
     return rc;
+}
+
+// Formats device bytes as PPM text into device memory; *length gets the text size.  d_work holds
+// height + 1 counters.  Synchronises the stream (the caller needs the length).
+static int ppm_encode_device(const uint8_t* d_rgb8, int width, int height, char* d_text, unsigned long long capacity,
+                             unsigned long long* d_work, unsigned long long* length, hipStream_t stream) {
+    char header[64];
+    const int hn = std::snprintf(header, sizeof header, "P3\n%d %d\n255\n", width, height);  // canvas.rs:66-72
+    const unsigned blocks = (unsigned)((height + 63) / 64);
+    hipLaunchKernelGGL(ppm_measure_kernel, dim3(blocks), dim3(64), 0, stream, d_rgb8, width, height, d_work);
+    hipLaunchKernelGGL(ppm_scan_kernel, dim3(1), dim3(64), 0, stream, height, (unsigned long long)hn, d_work);
+    hipLaunchKernelGGL(ppm_write_kernel, dim3(blocks), dim3(64), 0, stream, d_rgb8, width, height, d_work, capacity, d_text);
+    HIP_TRY(hipGetLastError());
+    unsigned long long total = 0;
+    HIP_TRY(hipMemcpyAsync(&total, d_work + height, sizeof total, hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    *length = total;
+    if (total > capacity) return fail(RT_ERR_LIMIT, "PPM text does not fit the buffer; *length holds the size needed");
+    HIP_TRY(hipMemcpyAsync(d_text, header, (size_t)hn, hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return RT_OK;
+}
+
+int rt_ppm_encode(int device, const uint8_t* rgb8, int32_t width, int32_t height, char* text_out, uint64_t capacity,
+                  uint64_t* length) {
+    if (width <= 0 || height <= 0 || !rgb8 || !length || (capacity && !text_out))
+        return fail(RT_ERR_INVALID, "bad arguments");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
+    if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "device ordinal out of range");
+    HIP_TRY(hipSetDevice(device));
+    const size_t in_bytes = (size_t)width * height * 3;
+    uint8_t* d_in = nullptr;
+    char* d_text = nullptr;
+    unsigned long long* d_work = nullptr;
+    int rc = RT_OK;
+    if (hipMalloc((void**)&d_in, in_bytes) != hipSuccess || hipMalloc((void**)&d_text, capacity ? capacity : 1) != hipSuccess ||
+        hipMalloc((void**)&d_work, ((size_t)height + 1) * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemcpy(d_in, rgb8, in_bytes, hipMemcpyHostToDevice) != hipSuccess) {
+        rc = fail(RT_ERR_HIP, "device allocation or copy failed");
+    } else {
+        unsigned long long total = 0;
+        rc = ppm_encode_device(d_in, width, height, d_text, capacity, d_work, &total, nullptr);
+        *length = total;
+        if (rc == RT_OK && hipMemcpy(text_out, d_text, (size_t)total, hipMemcpyDeviceToHost) != hipSuccess)
+            rc = fail(RT_ERR_HIP, "hipMemcpy of the PPM text failed");
+    }
+    if (d_in) (void)hipFree(d_in);
+    if (d_text) (void)hipFree(d_text);
+    if (d_work) (void)hipFree(d_work);
+    return rc;
+}
+
+int rt_render_ppm(rt_scene* s, const rt_camera* cam, const rt_params* prm, char* text_out, uint64_t capacity,
+                  uint64_t* length, rt_stats* stats) {
+    if (!s || !cam || !length || (capacity && !text_out)) return fail(RT_ERR_INVALID, "bad arguments");
+    int rc = check_params(prm);
+    if (rc != RT_OK) return rc;
+    if (prm->world_size != 1) return fail(RT_ERR_INVALID, "rt_render_ppm renders whole frames: world_size must be 1");
+    if (cam->width <= 0 || cam->height <= 0) return fail(RT_ERR_INVALID, "empty canvas");
+    HIP_TRY(hipSetDevice(s->device));
+    // staging: bytes of the frame, row counters, text
+    const size_t frame = (size_t)cam->width * cam->height * 3;
+    const size_t work = ((size_t)cam->height + 1) * sizeof(unsigned long long);
+    const size_t need = ((frame + 255) & ~(size_t)255) + ((work + 255) & ~(size_t)255) + (capacity ? capacity : 1);
+    if (need > s->frame_bytes) {
+        if (s->d_frame) HIP_TRY(hipFree(s->d_frame));
+        s->d_frame = nullptr;
+        s->frame_bytes = 0;
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, need));
+        s->d_frame = (double*)p;
+        s->frame_bytes = need;
+    }
+    uint8_t* d_rgb8 = reinterpret_cast<uint8_t*>(s->d_frame);
+    unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_rgb8 + ((frame + 255) & ~(size_t)255));
+    char* d_text = reinterpret_cast<char*>(d_work) + ((work + 255) & ~(size_t)255);
+    rc = render_device(s, cam, prm, d_rgb8, true, nullptr);
+    if (rc != RT_OK) return rc;
+    unsigned long long total = 0;
+    rc = ppm_encode_device(d_rgb8, cam->width, cam->height, d_text, capacity, d_work, &total, nullptr);
+    *length = total;
+    if (rc != RT_OK) return rc;
+    HIP_TRY(hipMemcpy(text_out, d_text, (size_t)total, hipMemcpyDeviceToHost));
+    return fill_stats(s, stats);
 }
 
 int rt_scene_launch_times(rt_scene* s, float* ms, int cap) {

@@ -172,3 +172,34 @@ def test_cyclic_tiles_u8_reassemble(host, world_size):
         part = host.render_u8(mw(host), mc(host, W, H), rank=rank, world_size=world_size)
         frame[host.global_rows(H, rank, world_size)] = part
     assert np.array_equal(frame, full)
+
+
+def test_ppm_text_on_device(host, orc):
+    """Canvas::to_ppm on the device (rt_ppm_encode, rt_render_ppm) against the two CPU writers, on
+    the reference's own known answers (canvas.rs:172-218: a 5x3 canvas, and a 10x2 canvas whose
+    rows need wrapping at 70 columns) and on images whose values have every mix of digit counts."""
+    c = np.zeros((3, 5, 3))
+    c[0, 0], c[1, 2], c[2, 4] = (1.5, 0, 0), (0, 0.5, 0), (-0.5, 0, 1)
+    q = quantise(c).astype(np.uint8)
+    text = host.ppm_encode(q)
+    assert text == (b"P3\n5 3\n255\n255 0 0 0 0 0 0 0 0 0 0 0 0 0 0\n0 0 0 0 0 0 0 128 0 0 0 0 0 0 0\n"
+                    b"0 0 0 0 0 0 0 0 0 0 0 0 0 0 255\n")
+    wide = quantise(np.tile(np.array([1.0, 0.8, 0.6]), (2, 10, 1))).astype(np.uint8)
+    text = host.ppm_encode(wide)
+    line1 = b"255 204 153 255 204 153 255 204 153 255 204 153 255 204 153 255 204\n"
+    line2 = b"153 255 204 153 255 204 153 255 204 153 255 204 153\n"
+    assert text == b"P3\n10 2\n255\n" + (line1 + line2) * 2
+    rng = np.random.default_rng(2)
+    for shape in ((1, 1), (7, 23), (64, 17), (130, 5), (33, 200)):
+        for hi in (10, 100, 256):   # all 1-digit, 1-2 digits, 1-3 digits: different line breaks
+            img8 = rng.integers(0, hi, size=shape + (3,), dtype=np.uint8)
+            assert host.ppm_encode(img8) == host.to_ppm(img8) == orc.to_ppm(img8.astype(np.float64) / 255.0 - 1e-12 * (img8 > 0))
+    # a rendered frame end to end, and the size query when the buffer is too small
+    W, H = 120, 80
+    mw, mc = scenes.WORKLOADS["default"]
+    text = host.render_ppm(mw(host), mc(host, W, H))
+    assert text == host.to_ppm(host.render(mw(host), mc(host, W, H)))
+    from raytracer_amd import abi
+    with pytest.raises(abi.RtError) as e:
+        host.ppm_encode(wide, capacity=20)
+    assert e.value.code == abi.RT_ERR_LIMIT and e.value.needed == len(b"P3\n10 2\n255\n" + (line1 + line2) * 2)
