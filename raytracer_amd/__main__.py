@@ -11,9 +11,10 @@ def main(argv):
         return 1
     path, width, height = argv[1], int(argv[2]), int(argv[3])
     rt = api.load()
-    img = rt.render(scenes.build_world(rt), scenes.default_camera(rt, width, height))
+    # render and Canvas::to_ppm both run on the device; only the text comes back
+    text = rt.render_ppm(scenes.build_world(rt), scenes.default_camera(rt, width, height))
     with open(path, "wb") as f:
-        f.write(rt.to_ppm(img))
+        f.write(text)
     return 0
 
 
