@@ -99,6 +99,8 @@ def main():
     ap.add_argument("--gather", choices=["u8", "f64"], default="u8",
                     help="N > 1: what rank 0 collects per frame: the clamped bytes the PPM prints (default) or the f64 colours")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
+    ap.add_argument("--gather-mode", choices=["p2p", "collective"], default="p2p",
+                    help="N > 1: grouped send/recv of exactly each rank's rows (default) or one padded dist.gather")
     args = ap.parse_args()
 
     import torch
@@ -138,7 +140,7 @@ def main():
     buffers = [torch.empty((rows, W, 3), dtype=dtype, device=dev) for _ in range(2 if world_size > 1 else 1)]
 
     from raytracer_amd.distributed import FrameGather, OverlappedGather
-    gather = FrameGather(host, W, H, rank, world_size, dev, dtype=dtype) if world_size > 1 else None
+    gather = FrameGather(host, W, H, rank, world_size, dev, dtype=dtype, mode=args.gather_mode) if world_size > 1 else None
     pipe = OverlappedGather(gather, buffers) if gather is not None and not args.no_overlap else None
 
     def render(buf):

@@ -18,9 +18,14 @@ import torch.distributed as dist
 
 
 class FrameGather:
-    def __init__(self, host, width, height, rank, world_size, device, dst=0, dtype=torch.float64):
+    def __init__(self, host, width, height, rank, world_size, device, dst=0, dtype=torch.float64, mode="p2p"):
+        """mode "p2p": grouped send/recv, each rank sends exactly its rows.  mode "collective": one
+        dist.gather of buffers padded to the largest rank's row count (a plain collective, for
+        stacks where grouped point-to-point is not available)."""
         self.rank, self.world_size, self.dst = rank, world_size, dst
         self.dtype = dtype
+        self.mode = mode
+        self.padded = None
         self.width, self.height = width, height
         self.rows = [host.local_rows(height, r, world_size) for r in range(world_size)]
         self.frame = None
@@ -38,6 +43,8 @@ class FrameGather:
         assert tuple(local.shape) == (self.rows[self.rank], self.width, 3) and local.dtype == self.dtype
         if self.world_size > 1 and local.is_cuda and dist.get_backend() == "gloo":
             return self._staged(local)  # rehearsal only: gloo moves host memory
+        if self.world_size > 1 and self.mode == "collective":
+            return self._collective(local)
         if self.world_size > 1:
             if self.rank == self.dst:
                 ops = [dist.P2POp(dist.irecv, self.parts[r], r) for r in range(self.world_size)
@@ -48,6 +55,21 @@ class FrameGather:
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
         return self._place(local)
+
+    def _collective(self, local):
+        most = max(self.rows)
+        if self.padded is None:
+            self.padded = torch.zeros((most, self.width, 3), dtype=self.dtype, device=local.device)
+            self.slots = ([torch.empty_like(self.padded) for _ in range(self.world_size)]
+                          if self.rank == self.dst else None)
+        self.padded[: self.rows[self.rank]].copy_(local)
+        dist.gather(self.padded, self.slots, dst=self.dst)
+        if self.rank != self.dst:
+            return None
+        for r in range(self.world_size):
+            if self.rows[r] > 0:
+                self.frame.index_copy_(0, self.index[r], self.slots[r][: self.rows[r]])
+        return self.frame
 
     def _staged(self, local):
         if self.rank == self.dst:

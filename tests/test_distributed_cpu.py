@@ -58,7 +58,7 @@ def test_gather_reassembles_frame(tmp_path, world_size, size):
     assert np.array_equal(frame, full)
 
 
-def _worker_u8(rank, world_size, port, W, H, out_path):
+def _worker_u8(rank, world_size, port, W, H, out_path, mode="p2p"):
     """Byte frames through OverlappedGather (its CPU form): three frames in a row, each different, so
     that a buffer mix-up between consecutive frames would show."""
     sys.path.insert(0, ROOT)
@@ -70,7 +70,7 @@ def _worker_u8(rank, world_size, port, W, H, out_path):
         from raytracer_amd.distributed import FrameGather, OverlappedGather
         host = api.load()
         rows = host.global_rows(H, rank, world_size)
-        gather = FrameGather(host, W, H, rank, world_size, torch.device("cpu"), dtype=torch.uint8)
+        gather = FrameGather(host, W, H, rank, world_size, torch.device("cpu"), dtype=torch.uint8, mode=mode)
         bufs = [torch.empty((len(rows), W, 3), dtype=torch.uint8) for _ in range(2)]
         pipe = OverlappedGather(gather, bufs)
         frames = []
@@ -93,11 +93,12 @@ def _worker_u8(rank, world_size, port, W, H, out_path):
         dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("mode", ["p2p", "collective"])
 @pytest.mark.parametrize("world_size,size", [(2, (16, 37)), (3, (12, 50))])
-def test_overlapped_byte_gather(tmp_path, world_size, size):
+def test_overlapped_byte_gather(tmp_path, world_size, size, mode):
     W, H = size
     out = str(tmp_path / "frames.npy")
-    mp.spawn(_worker_u8, args=(world_size, _free_port(), W, H, out), nprocs=world_size, join=True)
+    mp.spawn(_worker_u8, args=(world_size, _free_port(), W, H, out, mode), nprocs=world_size, join=True)
     frames = np.load(out)
     yy, xx, cc = np.meshgrid(np.arange(H), np.arange(W), np.arange(3), indexing="ij")
     for k in range(3):
