@@ -980,8 +980,8 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
             unsigned long long base = 0;
             if (lane == leader) base = atomicAdd(&class_count[c], (unsigned long long)__builtin_popcountll(mask));
             base = (unsigned long long)__shfl((long long)base, leader, 64);
-            if (active && cls == c)
-                order[(long long)c * n_tiles + (long long)base + __builtin_popcountll(mask & ((1ull << lane) - 1ull))] = (int)tile;
+            const long long pos = (long long)base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
+            if (active && cls == c && pos < n_tiles) order[(long long)c * n_tiles + pos] = (int)tile;
         }
     }
 }
@@ -997,9 +997,12 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, i
     const long long n_tiles = (long long)J.tiles_x * J.local_tile_rows;
     if (J.tile_order && tile < n_tiles) {
         // expensive classes first: class 2, then 1, then 0
-        const long long n2 = (long long)J.tile_class_count[2], n1 = (long long)J.tile_class_count[1];
+        long long n2 = (long long)J.tile_class_count[2], n1 = (long long)J.tile_class_count[1];
+        n2 = n2 < n_tiles ? n2 : n_tiles;  // the three counts add up to n_tiles; clamped so that no index below can leave its array
+        n1 = n1 < n_tiles - n2 ? n1 : n_tiles - n2;
         tile = tile < n2 ? J.tile_order[2 * n_tiles + tile]
                          : (tile < n2 + n1 ? J.tile_order[n_tiles + (tile - n2)] : J.tile_order[tile - n2 - n1]);
+        if (tile < 0 || tile >= n_tiles) tile = n_tiles;  // never trust a table for an address: renders nothing
     }
     const int tx = (int)(tile % J.tiles_x);
     lty = (int)(tile / J.tiles_x);
@@ -1015,7 +1018,10 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
     const int wave = threadIdx.x >> 6;
     // The scene keeps two sets of ray counters; this launch clears the set the next launch will
     // use, which saves a memset (and its launch gap) per frame.
-    if (clear_counters && blockIdx.x < COUNTER_SET_WORDS / RT_BLOCK) clear_counters[blockIdx.x * RT_BLOCK + threadIdx.x] = 0ull;
+    {
+        const unsigned word = blockIdx.x * RT_BLOCK + threadIdx.x;
+        if (clear_counters && word < COUNTER_SET_WORDS) clear_counters[word] = 0ull;
+    }
     // A lane parks its finished pixel in LDS instead of carrying it through the rest of the
     // wavefront's rounds; the tile is written from there at the end.
     __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
@@ -2046,7 +2052,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
     unsigned long long* mine = s->d_counters + (size_t)a * COUNTER_SET_WORDS;
     unsigned long long* other = s->d_counters + (size_t)b * COUNTER_SET_WORDS;
     if (!s->set_clean[a]) HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), stream));
-    const bool clears_other = blocks >= COUNTER_SET_WORDS / RT_BLOCK;
+    const bool clears_other = blocks >= (COUNTER_SET_WORDS + RT_BLOCK - 1) / RT_BLOCK;  // enough threads to reach every word
     const long long tiles = job.n_rays > 0 ? 0 : (long long)job.tiles_x * job.local_tile_rows;
     static const bool order_enabled = !(getenv("RT_TILE_ORDER") && atoi(getenv("RT_TILE_ORDER")) == 0);
     job.tile_order = nullptr;
