@@ -10,7 +10,7 @@ A step renders one frame from tables already resident in HBM into HBM (at N > 1 
 ranks' tiles into rank 0's full frame).  Rank 0 prints ONE JSON line.
 
 `roofline` prices the render kernel against the FP64 vector peak: achieved = algorithmic f64
-operations of the frame (counted by the CPU oracle, profiles/work_*.json; constants in DESIGN.md)
+operations of the frame (counted by the CPU oracle with fixed per-event costs, profiles/work_*.json)
 / the kernel's mean device time from HIP events on its launch stream.
 `cpu_baseline` times the CPU restatement of the reference in its cost-faithful mode (inverse
 recomputed per use, secondary rays re-traced per light, 12 worker threads like src/lib.rs:23) on a

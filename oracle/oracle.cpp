@@ -49,7 +49,7 @@ struct Counters {
              pattern_nodes = 0, inverses = 0;
     // Algorithmic f64 operations of the deduplicated path (one per add/sub/mul/div/sqrt/min/max/
     // abs/compare/pow/cos on 3-component vectors and 3x4 affine matrices), accumulated with the
-    // per-event constants documented in DESIGN.md; and the non-identity ray transforms.
+    // per-event constants written next to each `g_cnt.flops +=`; and the non-identity ray transforms.
     uint64_t flops = 0, xform_nonident = 0;
     void add(const Counters& o) {
         const uint64_t* s = reinterpret_cast<const uint64_t*>(&o);
