@@ -61,10 +61,11 @@ namespace {
 // index where its right operand starts, the operation in bits 12-13).  Between them the leaves collect their intersections per lane instead
 // of competing for the nearest hit; the end record sorts and filters them.
 enum { T_XFORM = 8, T_CULL = 9, T_CSG_BEGIN = 10, T_CSG_END = 11, T_HAS_INV = 0x100, T_CLOSED = 0x200,
-       T_OWN_XFORM = 0x400, T_CSG_OP_SHIFT = 12 };
+       T_OWN_XFORM = 0x400, T_LINE_ONLY = 0x800, T_CSG_OP_SHIFT = 12 };
 struct alignas(16) TRec {
     int kind;    // low byte: RT_* type or T_XFORM; T_HAS_INV: p holds rows 0..2 of the inverse; T_CLOSED;
-                 // T_OWN_XFORM: the record before this one is this node's T_XFORM record
+                 // T_OWN_XFORM: the record before this one is this node's T_XFORM record;
+                 // T_LINE_ONLY (groups): hits below can lie outside the box, test the ray's line only
     int skip;    // first record after this node's subtree
     int ctx;     // record holding the inverse of the nearest enclosing transformed group, or -1
     int node;    // index into the node table (what a hit reports)
@@ -581,7 +582,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // only yield times that do not count are skipped: behind the origin (unless the n1/n2
             // bookkeeping needs the times <= 0), beyond the light, beyond the nearest hit so far.
             // tpad absorbs the rounding between a child's time and its group's box times.
-            if (!CSGM || csg_depth == 0) {  // inside a CSG shape its filter needs every intersection
+            if ((!CSGM || csg_depth == 0) && !(kind & T_LINE_ONLY)) {  // inside a CSG shape its filter needs every intersection
                 if (!TRACK) inside = inside && !(tmax < -tpad);
                 if (MODE == MODE_SHADOW) inside = inside && !(tmin > limit + tpad);
                 if (!TRACK) inside = inside && !(h.found && tmin > h.t + tpad);
@@ -1728,21 +1729,14 @@ bool affine_forward(const double inv[12], double fwd[12]) {
     return true;
 }
 
-// Fills a T_CULL record for the box [bmin, bmax]; smin / smax are the smallest / largest stretch of
-// the leaf's object-to-parent map (1 for untransformed triangles).
-bool fill_cull(const double bmin[3], const double bmax[3], double smin, double smax, TRec& out) {
+// Fills a T_CULL record for the box [bmin, bmax].  far_term: see NodeBox::far.
+bool fill_cull(const double bmin[3], const double bmax[3], double far_term, TRec& out) {
     double size = 0.0, reach = 0.0;
     for (int k = 0; k < 3; ++k) {
         size = std::fmax(size, bmax[k] - bmin[k]);
         reach = std::fmax(reach, std::fmax(std::fabs(bmin[k]), std::fabs(bmax[k])));
     }
-    if (!std::isfinite(size) || !std::isfinite(reach) || !(smin > 0.0) || !std::isfinite(smax)) return false;
-    // A ray origin at distance D is at most D / smin from the leaf in object space, where the
-    // quadratic's discriminant carries an error of about 10 eps (D / smin)^2; a line that misses
-    // the unit shape by less than half of that can still be reported as a hit, which is up to
-    // smax times as far in this space.  10^-9 leaves six orders of magnitude over eps.  (The
-    // triangle test has no such cancellation; the same padding is simply generous for it.)
-    const double far_term = 1e-9 * smax / (smin * smin);
+    if (!std::isfinite(size) || !std::isfinite(reach) || !std::isfinite(far_term)) return false;
     out.kind = T_CULL;
     out.r0 = 1e-6 * (size + reach) + 2.0 * far_term * reach * reach;  // |o - c|^2 <= 2 |o|^2 + 2 reach^2
     out.r1 = 2.0 * far_term;
@@ -1754,125 +1748,264 @@ bool fill_cull(const double bmin[3], const double bmax[3], double smin, double s
     return true;
 }
 
-// The T_CULL record of a finite sphere, cube or cylinder leaf, or false when the leaf is unbounded
-// (open-ended cylinders) or its transform is too degenerate to bound.
-bool cull_record(const rt_scene_desc* d, const rt_node& n, TRec& out) {
-    // Cones are left out: for a ray parallel to one half of the cone the reference reports the
-    // single wall intersection without the minimum < y < maximum check (cone.rs:119-127), so a
-    // truncated cone can be hit outside any box around it.
-    double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};
-    if (n.type == RT_CYLINDER) {
-        const double mn = d->ranges[n.data].minimum, mx = d->ranges[n.data].maximum;
-        if (!std::isfinite(mn) || !std::isfinite(mx)) return false;
-        lo[1] = std::fmin(mn, mx);
-        hi[1] = std::fmax(mn, mx);
-    } else if (n.type != RT_SPHERE && n.type != RT_CUBE) {
-        return false;
-    }
-    double fwd[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    if (n.xform >= 0 && !affine_forward(d->xforms[n.xform].inv, fwd)) return false;
-    double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int corner = 0; corner < 8; ++corner) {
-        const double x = (corner & 1) ? hi[0] : lo[0], y = (corner & 2) ? hi[1] : lo[1], z = (corner & 4) ? hi[2] : lo[2];
-        for (int row = 0; row < 3; ++row) {
-            const double v = fwd[row * 4] * x + fwd[row * 4 + 1] * y + fwd[row * 4 + 2] * z + fwd[row * 4 + 3];
-            bmin[row] = std::fmin(bmin[row], v);
-            bmax[row] = std::fmax(bmax[row], v);
-        }
-    }
-    double smin = INFINITY, smax = 0.0;
-    for (int k = 0; k < 3; ++k) {
-        const double col = std::sqrt(fwd[k] * fwd[k] + fwd[4 + k] * fwd[4 + k] + fwd[8 + k] * fwd[8 + k]);
-        smin = std::fmin(smin, col);
-        smax = std::fmax(smax, col);
-    }
-    return fill_cull(bmin, bmax, smin, smax, out);
-}
+// A node's box in its parent's space, for T_CULL records.
+struct NodeBox {
+    double mn[3], mx[3];
+    // A ray origin at distance D is at most D / smin from a leaf in its object space (smin, smax:
+    // smallest / largest stretch of the object-to-here map), where the quadratic's discriminant
+    // carries an error of about 10 eps (D / smin)^2; a line that misses the unit shape by less
+    // than half of that can still be reported as a hit, which is up to smax times as far in this
+    // space.  far = 1e-9 smax / smin^2 (the largest over the leaves below a group) leaves six
+    // orders of magnitude over eps.  (The triangle test has no such cancellation; the same padding
+    // is simply generous for it.)
+    double far;
+    bool ok;  // false: unbounded, or a transform too degenerate to bound
+};
 
-// One T_CULL record in front of a run of sibling triangles [lo, hi) that have no transform of their
-// own: the box around all of them, in their parent's space.  Long runs come from Group::divide
-// (group.rs:79-105), which leaves every triangle that straddles a split plane in the parent.
-bool cluster_cull_record(const rt_scene_desc* d, int lo, int hi, TRec& out) {
-    double bmin[3] = {INFINITY, INFINITY, INFINITY}, bmax[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int i = lo; i < hi; ++i) {
-        const rt_tri& t = d->tris[d->nodes[i].data];
-        for (int k = 0; k < 3; ++k) {
-            const double a = t.p1[k], b = t.p1[k] + t.e1[k], c = t.p1[k] + t.e2[k];  // p1, p2, p3 up to an ulp
-            bmin[k] = std::fmin(bmin[k], std::fmin(a, std::fmin(b, c)));
-            bmax[k] = std::fmax(bmax[k], std::fmax(a, std::fmax(b, c)));
-        }
-    }
-    return fill_cull(bmin, bmax, 1.0, 1.0, out);
-}
-
-// Lays the node table out as traversal records (see TRec).
-std::vector<TRec> build_records(const rt_scene_desc* d) {
+// Boxes of all nodes, and which nodes are or contain a cone.
+void node_boxes(const rt_scene_desc* d, std::vector<NodeBox>& box, std::vector<char>& cone_below) {
     const int N = d->n_nodes;
-    static const bool no_cull = getenv("RT_NO_CULL") && atoi(getenv("RT_NO_CULL")) != 0;
-    std::vector<TRec> out;
-    // Skip links are node indices while the records are being emitted and are turned into record
-    // indices at the end, when pre[] is known:  record skip = pre[skip_node] + skip_extra.
-    //   pre[k]: index of the first record emitted on reaching node k (before the end records of
-    //           the CSG shapes that close at k); rec[k]: first record of node k itself.
-    // A CSG shape's end record follows its last descendant.  Several shapes can end at the same
-    // node index k (each the last child of the one before); their end records come innermost
-    // first.  A skip over node X must land after the end records of the CSG shapes inside X (or X
-    // itself) and before those of the shapes around X: skip_extra = ends_inside[X].
-    std::vector<int> last_child(N, -1), ends_inside(N, 0), pre(N + 1, -1), rec(N + 1, -1);
-    std::vector<int> skip_node, skip_extra;  // per record; skip_node < 0: the record's skip field is final
-    for (int c = 0; c < N; ++c) {
-        const int p = d->nodes[c].parent;
-        if (p >= 0 && d->nodes[c].skip == d->nodes[p].skip) last_child[p] = c;
-    }
-    for (int x = N - 1; x >= 0; --x)
-        ends_inside[x] = (d->nodes[x].type == RT_CSG ? 1 : 0) + (last_child[x] >= 0 ? ends_inside[last_child[x]] : 0);
-    auto push = [&](const TRec& r, int node_skip, int extra) {
-        out.push_back(r);
-        skip_node.push_back(node_skip);
-        skip_extra.push_back(extra);
-    };
-    auto own_payload = [&](const rt_node& n) {
-        return n.type == RT_GROUP || n.type == RT_CSG || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
-    };
-    auto plain_triangle = [&](int i) {
+    box.assign(N, NodeBox{});
+    cone_below.assign(N, 0);
+    std::vector<double> far_below(N, 0.0);  // per container: largest `far` of its children
+    for (int i = N - 1; i >= 0; --i) {      // children come after their parent
         const rt_node& n = d->nodes[i];
-        return (n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE) && n.xform < 0;
-    };
-    auto ctx_record = [&](const rt_node& n) { return n.ctx >= 0 ? rec[n.ctx] : -1; };  // ancestors are already emitted
-
-    std::vector<int> open;  // CSG shapes whose end record is still to come
-    auto close_until = [&](int k) {
-        while (!open.empty() && d->nodes[open.back()].skip == k) {
-            const int c = open.back();
-            open.pop_back();
-            const rt_node& n = d->nodes[c];
-            TRec e{};
-            e.kind = T_CSG_END | (((n.flags & RT_NODE_CSG_OP_MASK) >> 4) << T_CSG_OP_SHIFT);
-            e.node = c;
-            e.skip = d->nodes[c + 1].skip;  // NODE index where the right operand starts
-            e.ctx = n.xform >= 0 ? rec[c] : ctx_record(n);
-            push(e, -1, 0);
+        NodeBox& b = box[i];
+        double lo[3] = {-1.0, -1.0, -1.0}, hi[3] = {1.0, 1.0, 1.0};
+        double below = 1e-9;
+        b.ok = true;
+        if (n.type == RT_CONE) cone_below[i] = 1;
+        switch (n.type) {
+            case RT_SPHERE:
+            case RT_CUBE:
+                break;
+            case RT_CYLINDER: {
+                const double mn = d->ranges[n.data].minimum, mx = d->ranges[n.data].maximum;
+                lo[1] = std::fmin(mn, mx);
+                hi[1] = std::fmax(mn, mx);
+                break;
+            }
+            case RT_TRIANGLE:
+            case RT_SMOOTH_TRIANGLE: {
+                const rt_tri& t = d->tris[n.data];
+                for (int k = 0; k < 3; ++k) {
+                    const double p = t.p1[k], q = t.p1[k] + t.e1[k], r = t.p1[k] + t.e2[k];  // p1, p2, p3 up to an ulp
+                    lo[k] = std::fmin(p, std::fmin(q, r));
+                    hi[k] = std::fmax(p, std::fmax(q, r));
+                }
+                break;
+            }
+            case RT_GROUP:
+            case RT_CSG:
+                std::memcpy(lo, d->aabbs[n.data].min, sizeof lo);
+                std::memcpy(hi, d->aabbs[n.data].max, sizeof hi);
+                below = std::fmax(far_below[i], 1e-9);
+                break;
+            default:
+                // Planes are unbounded.  Cones are left out: for a ray parallel to one half of the
+                // cone the reference reports the single wall intersection without the
+                // minimum < y < maximum check (cone.rs:119-127), so a truncated cone can be hit
+                // outside any box around it.
+                b.ok = false;
         }
-    };
-    auto emit_node = [&](int i) {
+        for (int k = 0; k < 3; ++k)
+            if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) b.ok = false;
+        double fwd[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+        if (b.ok && n.xform >= 0 && !affine_forward(d->xforms[n.xform].inv, fwd)) b.ok = false;
+        double smin = INFINITY, smax = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            const double col = std::sqrt(fwd[k] * fwd[k] + fwd[4 + k] * fwd[4 + k] + fwd[8 + k] * fwd[8 + k]);
+            smin = std::fmin(smin, col);
+            smax = std::fmax(smax, col);
+        }
+        b.far = below * smax / (smin * smin);
+        if (!(smin > 0.0) || !std::isfinite(b.far)) b.ok = false;
+        if (b.ok) {
+            for (int k = 0; k < 3; ++k) {
+                b.mn[k] = INFINITY;
+                b.mx[k] = -INFINITY;
+            }
+            for (int corner = 0; corner < 8; ++corner) {
+                const double x = (corner & 1) ? hi[0] : lo[0], y = (corner & 2) ? hi[1] : lo[1],
+                             z = (corner & 4) ? hi[2] : lo[2];
+                for (int row = 0; row < 3; ++row) {
+                    const double v = fwd[row * 4] * x + fwd[row * 4 + 1] * y + fwd[row * 4 + 2] * z + fwd[row * 4 + 3];
+                    b.mn[row] = std::fmin(b.mn[row], v);
+                    b.mx[row] = std::fmax(b.mx[row], v);
+                }
+            }
+        }
+        if (n.parent >= 0) {
+            far_below[n.parent] = std::fmax(far_below[n.parent], std::isfinite(b.far) ? b.far : 0.0);
+            if (cone_below[i]) cone_below[n.parent] = 1;
+        }
+    }
+}
+
+// Lays the node table out as traversal records (see TRec), depth first in node order.
+//
+// T_CULL records go in front of (a) a finite sphere, cube or cylinder leaf and (b) runs of at least
+// CLUSTER_MIN consecutive siblings that all have finite boxes (leaves, groups, CSG shapes), and of
+// the halves of such runs, recursively: a wavefront whose rays all miss a box skips that part of the
+// run.  Long runs come from scenes built without groups and from Group::divide (group.rs:79-105),
+// which leaves every child that straddles a split plane in the parent.  A run is cut where the two
+// parts' boxes are cheapest to visit (surface area times count, the usual estimate of how many rays
+// reach a box).  The order of the leaves, which breaks ties between equal times, is untouched.
+// A box that is not clearly smaller than the one the ray has just passed (the enclosing group's or
+// run's) is not worth a record and is left out.
+struct RecordBuilder {
+    static constexpr int CLUSTER_MIN = 2;
+    // Tuned on the default scene, a scene of loose quadrics and three divided meshes (870 k
+    // triangles the largest); the frame times move by a few percent over 1..4, 1..3, 1.5..4, 0.3..0.9.
+    static constexpr double need = 2.0;        // expected saved visits a run's box must reach
+    static constexpr double cost_quad = 1.0;   // visit costs in units of one T_CULL test: a leaf's own T_CULL record,
+    static constexpr double cost_tri = 1.5;    // a triangle test,
+    static constexpr double cost_group = 2.5;  // a group's or CSG shape's exact bounds test
+    static constexpr double worth = 0.5;       // a leaf's box must have at most this share of the enclosing box's area
+
+    const rt_scene_desc* d;
+    bool no_cull;
+    std::vector<TRec> out;
+    std::vector<int> rec;  // first record of each node (its T_XFORM record when it has one)
+    std::vector<NodeBox> box;
+    std::vector<char> cone_below;
+    std::vector<double> suffix_area;
+
+    static double area(const double mn[3], const double mx[3]) {
+        const double x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
+        return x * y + y * z + z * x;
+    }
+    static bool own_payload(const rt_node& n) {
+        return n.type == RT_GROUP || n.type == RT_CSG || n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE;
+    }
+    static bool container(const rt_node& n) { return n.type == RT_GROUP || n.type == RT_CSG; }
+    int ctx_record(const rt_node& n) const { return n.ctx >= 0 ? rec[n.ctx] : -1; }  // ancestors are already emitted
+    // Time-based pruning assumes every hit below a box lies inside it; the cone's unchecked wall
+    // intersection does not, so boxes over cones only test the ray's line, as the reference does.
+    bool boxable(int i) const { return box[i].ok && !(container(d->nodes[i]) && cone_below[i]); }
+    static void grow(double mn[3], double mx[3], const NodeBox& b) {
+        for (int k = 0; k < 3; ++k) {
+            mn[k] = std::fmin(mn[k], b.mn[k]);
+            mx[k] = std::fmax(mx[k], b.mx[k]);
+        }
+    }
+
+    int best_split(const std::vector<int>& sib, int lo, int hi) {
+        const int n = hi - lo;
+        if (n <= 2) return lo + n / 2;
+        suffix_area.assign(n + 1, 0.0);
+        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int k = n - 1; k >= 1; --k) {
+            grow(mn, mx, box[sib[lo + k]]);
+            suffix_area[k] = area(mn, mx);
+        }
+        double pmn[3] = {INFINITY, INFINITY, INFINITY}, pmx[3] = {-INFINITY, -INFINITY, -INFINITY};
+        int best = lo + n / 2;
+        double best_cost = INFINITY;
+        for (int k = 1; k < n; ++k) {
+            grow(pmn, pmx, box[sib[lo + k - 1]]);
+            const double cost = area(pmn, pmx) * k + suffix_area[k] * (n - k);
+            if (cost < best_cost) {
+                best_cost = cost;
+                best = lo + k;
+            }
+        }
+        return best;
+    }
+
+    // Rough cost of visiting a member of a run, in units of one T_CULL test.
+    double visit_cost(int i) const {
+        const rt_node& n = d->nodes[i];
+        if (container(n)) return cost_group;
+        if (n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE) return cost_tri;
+        return cost_quad;  // the leaf's own T_CULL record
+    }
+
+    // `enclosing`: area of the box the ray has already been tested against on the way here.
+    // Written with an explicit stack: the cheapest cut of a long run can be very uneven, and the
+    // depth of a recursion would then grow with the length of the run.
+    void emit_run(const std::vector<int>& sib, int lo0, int hi0, double enclosing0) {
+        struct Item {
+            int lo, hi;        // a part of the run, or (lo < 0) "set the skip link of record hi"
+            double enclosing;
+        };
+        std::vector<Item> todo{{lo0, hi0, enclosing0}};
+        while (!todo.empty()) {
+            const Item it = todo.back();
+            todo.pop_back();
+            if (it.lo < 0) {
+                out[it.hi].skip = (int)out.size();
+                continue;
+            }
+            if (it.hi - it.lo == 1) {
+                emit_subtree(sib[it.lo], it.enclosing);
+                continue;
+            }
+            double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+            double far = 0.0, cost = 0.0;
+            for (int k = it.lo; k < it.hi; ++k) {
+                grow(mn, mx, box[sib[k]]);
+                far = std::fmax(far, box[sib[k]].far);
+                cost += visit_cost(sib[k]);
+            }
+            double enclosing = it.enclosing;
+            const double a = area(mn, mx);
+            const double share = std::isfinite(enclosing) ? (enclosing > 0.0 ? a / enclosing : 1.0) : 0.0;
+            TRec c{};
+            // worth a record when the visits it is expected to save outweigh its own test
+            if (cost * (1.0 - share) >= need && fill_cull(mn, mx, far, c)) {
+                c.ctx = ctx_record(d->nodes[sib[it.lo]]);
+                c.node = sib[it.lo];
+                todo.push_back({-1, (int)out.size(), 0.0});
+                out.push_back(c);
+                enclosing = a;
+            }
+            const int mid = best_split(sib, it.lo, it.hi);
+            todo.push_back({mid, it.hi, enclosing});
+            todo.push_back({it.lo, mid, enclosing});
+        }
+    }
+
+    void emit_children(int first, int end, double enclosing) {
+        std::vector<int> sib;
+        for (int c = first; c < end; c = d->nodes[c].skip) sib.push_back(c);
+        const int n = (int)sib.size();
+        for (int a = 0; a < n;) {
+            int b = a;
+            if (!no_cull)
+                while (b < n && boxable(sib[b])) ++b;
+            if (b - a >= CLUSTER_MIN) {
+                emit_run(sib, a, b, enclosing);
+                a = b;
+            } else {
+                emit_subtree(sib[a], enclosing);
+                ++a;
+            }
+        }
+    }
+
+    void emit_subtree(int i, double enclosing) {
         const rt_node& n = d->nodes[i];
         TRec r{};
         r.ctx = ctx_record(n);
         r.node = i;
         int flags = (n.flags & RT_NODE_CLOSED) ? T_CLOSED : 0;
         rec[i] = (int)out.size();
+        int extra = -1;  // this node's T_XFORM or T_CULL record
         if (n.xform >= 0 && own_payload(n)) {
             TRec x = r;
             x.kind = T_XFORM | T_HAS_INV;
             std::memcpy(x.p, d->xforms[n.xform].inv, sizeof x.p);
-            push(x, n.skip, ends_inside[i]);
+            extra = (int)out.size();
+            out.push_back(x);
             flags |= T_OWN_XFORM;
             r.ctx = rec[i];  // the node itself is tested in its own space
-        } else {
+        } else if (!own_payload(n)) {
             TRec c = r;
-            if (!no_cull && cull_record(d, n, c)) {
-                c.skip = (int)out.size() + 2;  // past the leaf
-                push(c, -1, 0);
+            const NodeBox& b = box[i];
+            if (!no_cull && b.ok && area(b.mn, b.mx) <= worth * enclosing && fill_cull(b.mn, b.mx, b.far, c)) {
+                extra = (int)out.size();
+                out.push_back(c);
             }
             if (n.xform >= 0) {
                 flags |= T_HAS_INV;
@@ -1880,10 +2013,18 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
             }
         }
         r.kind = (n.type == RT_CSG ? (int)T_CSG_BEGIN : n.type) | flags;
-        if (n.type == RT_GROUP || n.type == RT_CSG) {
-            std::memcpy(r.p, d->aabbs[n.data].min, 3 * sizeof(double));
-            std::memcpy(r.p + 3, d->aabbs[n.data].max, 3 * sizeof(double));
-            if (n.type == RT_CSG) open.push_back(i);
+        double inner = INFINITY;
+        if (container(n)) {
+            const double* mn = d->aabbs[n.data].min;
+            const double* mx = d->aabbs[n.data].max;
+            std::memcpy(r.p, mn, 3 * sizeof(double));
+            std::memcpy(r.p + 3, mx, 3 * sizeof(double));
+            if (cone_below[i]) {
+                r.kind |= T_LINE_ONLY;
+            } else {
+                inner = area(mn, mx);
+                if (!std::isfinite(inner)) inner = INFINITY;  // NaN from inf - inf
+            }
         } else if (n.type == RT_CYLINDER || n.type == RT_CONE) {
             r.r0 = d->ranges[n.data].minimum;
             r.r1 = d->ranges[n.data].maximum;
@@ -1892,85 +2033,36 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
             std::memcpy(r.p + 3, d->tris[n.data].e1, 3 * sizeof(double));
             std::memcpy(r.p + 6, d->tris[n.data].e2, 3 * sizeof(double));
         }
-        push(r, n.skip, ends_inside[i]);
-    };
-    // A run [lo, hi) of sibling triangles gets a box, and so do its halves while they hold at least
-    // CLUSTER_MIN triangles: a wavefront whose rays all miss a box skips that part of the run.  The
-    // order of the leaves (which breaks ties between equal times) is untouched.
-    // The run is cut where the two parts' boxes are cheapest to visit (surface area times count,
-    // the usual estimate of how many rays reach a box), keeping the order of the leaves.
-    auto tri_box = [&](int i, double mn[3], double mx[3]) {
-        const rt_tri& t = d->tris[d->nodes[i].data];
-        for (int k = 0; k < 3; ++k) {
-            const double a = t.p1[k], b = t.p1[k] + t.e1[k], c = t.p1[k] + t.e2[k];
-            mn[k] = std::fmin(mn[k], std::fmin(a, std::fmin(b, c)));
-            mx[k] = std::fmax(mx[k], std::fmax(a, std::fmax(b, c)));
-        }
-    };
-    auto area = [](const double mn[3], const double mx[3]) {
-        const double x = mx[0] - mn[0], y = mx[1] - mn[1], z = mx[2] - mn[2];
-        return x * y + y * z + z * x;
-    };
-    std::vector<double> suffix_area;
-    auto best_split = [&](int lo, int hi) {
-        const int n = hi - lo;
-        if (n <= 2) return lo + n / 2;
-        suffix_area.assign(n + 1, 0.0);
-        double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        for (int k = n - 1; k >= 1; --k) {
-            tri_box(lo + k, mn, mx);
-            suffix_area[k] = area(mn, mx);
-        }
-        double pmn[3] = {INFINITY, INFINITY, INFINITY}, pmx[3] = {-INFINITY, -INFINITY, -INFINITY};
-        int best = lo + n / 2;
-        double best_cost = INFINITY;
-        for (int k = 1; k < n; ++k) {
-            tri_box(lo + k - 1, pmn, pmx);
-            const double cost = area(pmn, pmx) * k + suffix_area[k] * (n - k);
-            if (cost < best_cost) {
-                best_cost = cost;
-                best = lo + k;
+        const int at = (int)out.size();
+        out.push_back(r);
+        if (container(n)) {
+            emit_children(i + 1, n.skip, inner);
+            if (n.type == RT_CSG) {
+                // The end record follows the last descendant; a skip over a node inside this shape
+                // lands before it, a skip over the shape itself after it.
+                TRec e{};
+                e.kind = T_CSG_END | (((n.flags & RT_NODE_CSG_OP_MASK) >> 4) << T_CSG_OP_SHIFT);
+                e.node = i;
+                e.skip = d->nodes[i + 1].skip;  // NODE index where the right operand starts
+                e.ctx = n.xform >= 0 ? rec[i] : ctx_record(n);
+                out.push_back(e);
             }
         }
-        return best;
-    };
-    constexpr int CLUSTER_MIN = 2;  // measured on the dragon mesh: 2 beats 3, 4, 6, 8 (0.84 / 0.87 / 0.94 / 1.04 / 1.12 ms)
-    auto emit_run = [&](auto&& self, int lo, int hi) -> void {
-        if (pre[lo] < 0) pre[lo] = (int)out.size();
-        TRec c{};
-        if (hi - lo >= CLUSTER_MIN && cluster_cull_record(d, lo, hi, c)) {
-            c.ctx = ctx_record(d->nodes[lo]);
-            c.node = lo;
-            push(c, hi, 0);  // to the first record emitted for node hi
-            const int mid = best_split(lo, hi);
-            self(self, lo, mid);
-            self(self, mid, hi);
-            return;
-        }
-        for (int i = lo; i < hi; ++i) {
-            if (pre[i] < 0) pre[i] = (int)out.size();
-            emit_node(i);
-        }
-    };
-    for (int i = 0; i < N;) {
-        pre[i] = (int)out.size();
-        close_until(i);
-        int j = i;
-        if (!no_cull && plain_triangle(i))
-            while (j < N && plain_triangle(j) && d->nodes[j].parent == d->nodes[i].parent) ++j;
-        if (j - i >= CLUSTER_MIN) {
-            emit_run(emit_run, i, j);
-            i = j;
-        } else {
-            emit_node(i);
-            ++i;
-        }
+        const int after = (int)out.size();
+        out[at].skip = after;
+        if (extra >= 0) out[extra].skip = after;
     }
-    pre[N] = (int)out.size();
-    close_until(N);
-    for (size_t r = 0; r < out.size(); ++r)
-        if (skip_node[r] >= 0) out[r].skip = pre[skip_node[r]] + skip_extra[r];
-    return out;
+};
+
+std::vector<TRec> build_records(const rt_scene_desc* d) {
+    static const bool no_cull = getenv("RT_NO_CULL") && atoi(getenv("RT_NO_CULL")) != 0;
+    RecordBuilder b{};
+    b.d = d;
+    b.no_cull = no_cull;
+    b.rec.assign(d->n_nodes + 1, -1);
+    node_boxes(d, b.box, b.cone_below);
+    b.emit_children(0, d->n_nodes, INFINITY);
+    return std::move(b.out);
 }
 
 // Gathers per-leaf shading data (see SRec).

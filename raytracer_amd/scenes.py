@@ -207,7 +207,50 @@ def csg_world(api):
     return api.World([floor, die, lens, top], lights)
 
 
+def field_world(api, side=16):
+    """side x side small spheres, cubes and closed cylinders standing on a checkered floor, all
+    added to the world directly (no groups), the way scenes are usually written against
+    World::new; every tenth one is a mirror, every seventh is glass.  Build-defined; its oracle is
+    the CPU restatement."""
+    M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+    floor = api.Plane(M.identity(),
+                      Phong(api.Checker(Solid(Color(0.9, 0.9, 0.9)), Solid(Color(0.3, 0.3, 0.35)), M.identity()),
+                            0.1, 0.9, 0.0, 200.0, 0.1, 0.0, 1.0), True)
+    objects = [floor]
+    for k in range(side * side):
+        i, j = k % side, k // side
+        x, z = (i - (side - 1) / 2.0) * 1.2, (j - (side - 1) / 2.0) * 1.2
+        r = 0.3 + 0.15 * ((k * 7) % 5) / 4.0
+        colour = Color(0.25 + 0.7 * ((k * 3) % 7) / 6.0, 0.25 + 0.7 * ((k * 5) % 11) / 10.0, 0.25 + 0.7 * ((k * 2) % 5) / 4.0)
+        if k % 10 == 3:
+            mat = Phong(Solid(colour), 0.1, 0.4, 0.9, 200.0, 0.7, 0.0, 1.0)
+        elif k % 7 == 5:
+            mat = Phong(Solid(Color(0.05, 0.05, 0.08)), 0.0, 0.1, 1.0, 300.0, 0.5, 0.9, 1.5)
+        else:
+            mat = Phong(Solid(colour), 0.1, 0.8, 0.3, 80.0, 0.0, 0.0, 1.0)
+        kind = k % 3
+        if kind == 0:
+            objects.append(api.Sphere(M.translation(x, r, z) * M.scaling(r, r, r), mat, True))
+        elif kind == 1:
+            objects.append(api.Cube(M.translation(x, r, z) * M.rotation_y(0.1 * k) * M.scaling(r, r, r), mat, True))
+        else:
+            objects.append(api.Cylinder(M.translation(x, 0.0, z) * M.scaling(r, 1.0, r), mat, True, 0.0, 2.0 * r, True))
+    lights = [api.PointLight(api.point(-12.0, 14.0, -10.0), Color.white()),
+              api.PointLight(api.point(8.0, 9.0, -12.0), Color(0.3, 0.3, 0.3))]
+    return api.World(objects, lights)
+
+
+def field_camera(api, width, height):
+    M = api.Matrix
+    # aimed below and beside the field: with (height, width) in the order src/lib.rs:59-61 passes them,
+    # a wide frame's centre is up and to the right of the view axis
+    return api.Camera(height, width, math.pi / 3.0,
+                      M.view_transform(api.point(0.0, 11.0, -15.0), api.point(-4.5, -8.0, -2.0),
+                                       api.vector(0.0, 1.0, 0.0)))
+
+
 WORKLOADS = {
+    "field": (field_world, field_camera),
     "default": (build_world, default_camera),
     "glass": (glass_world, glass_camera),
     "teapot": (lambda api: mesh_world(api, "teapot"), mesh_camera),

@@ -270,14 +270,55 @@ def grouped_world(api, seed):
     return api.World([outer], flat.lights)
 
 
-@pytest.mark.parametrize("grouped", [False, True])
+def mixed_world(api, seed):
+    """Thirty-odd objects directly in the world, the way scenes are built without groups: finite
+    quadrics, transformed triangles, small transformed groups (some holding a cone), a CSG shape, and
+    a plane and a cone in between, which end the runs of siblings that share cluster boxes."""
+    rng = np.random.default_rng(3000 + seed)
+    M = api.Matrix
+    base = quadric_world(api, seed)
+    objects = list(base.objects)
+
+    def mat():
+        return api.Phong(api.Solid(api.Color(*rng.uniform(0, 1, 3))), 0.2, 0.7, 0.3, 50.0,
+                         float(rng.choice([0.0, 0.3])), float(rng.choice([0.0, 0.0, 0.7])), 1.5)
+
+    def place():
+        return M.translation(*rng.uniform(-4, 4, 3)) * M.rotation_y(rng.uniform(-3, 3)) * M.scaling(*rng.uniform(0.2, 0.8, 3))
+    for k in range(20):
+        kind = k % 5
+        if kind == 0:
+            pts = [api.point(*rng.uniform(-1, 1, 3)) for _ in range(3)]
+            objects.append(api.Triangle(*pts, place(), mat(), True))
+        elif kind == 1:
+            g = api.Group(place())
+            g.add_child(api.Sphere(M.translation(-1, 0, 0), mat(), True))
+            g.add_child(api.Cube(M.translation(1, 0, 0) * M.scaling(0.5, 0.5, 0.5), mat(), True))
+            if k % 2:
+                g.add_child(api.Cone(M.translation(0, 1.5, 0), mat(), True, -1.0, 0.0, bool(k % 4 == 1)))
+            objects.append(g)
+        elif kind == 2:
+            objects.append(api.CSG(api.DIFFERENCE, api.Cube(M.identity(), mat(), True),
+                                   api.Sphere(M.translation(0.4, 0.4, -0.4), mat(), True), place()))
+        elif kind == 3:
+            objects.append(api.Sphere(place(), mat(), True))
+        else:
+            objects.append(api.Cylinder(place(), mat(), True, -1.0, 1.0, True))
+        if k == 7:
+            objects.append(api.Plane(M.translation(0, -5, 0), mat(), True))
+        if k == 13:
+            objects.append(api.Cone(place(), mat(), True, -1.0, 0.5, True))
+    return api.World(objects, base.lights)
+
+
+@pytest.mark.parametrize("kind", ["flat", "grouped", "mixed"])
 @pytest.mark.parametrize("seed", list(range(8)))
-def test_culling_is_conservative(host, orc, seed, grouped):
+def test_culling_is_conservative(host, orc, seed, kind):
     """Rays from 10 to 10^7 units away aimed at and just past the silhouettes of the objects: the
-    padded boxes (single leaves, runs of triangles) and the pruning of groups by their box times
+    padded boxes (single leaves, runs of siblings) and the pruning of groups by their box times
     must keep every ray the exact arithmetic counts as a hit, including the false hits that
     cancellation produces for far origins."""
-    make = grouped_world if grouped else quadric_world
+    make = {"flat": quadric_world, "grouped": grouped_world, "mixed": mixed_world}[kind]
     rng = np.random.default_rng(seed)
     origins, dirs = [], []
     for dist in (10.0, 1e3, 1e5, 1e7):
@@ -301,6 +342,29 @@ def test_culling_is_conservative(host, orc, seed, grouped):
     err = np.abs(got[finite] - ref[finite]) / np.maximum(1.0, np.abs(ref[finite]))
     assert err.max() <= 1e-9, "seed %d: max rel err %.3e" % (seed, err.max())
     assert (ref[finite] != 0.0).any()
+
+
+def test_cone_in_group_hit_outside_its_box(host, orc):
+    """For a ray parallel to one half of a cone the reference reports the wall intersection without
+    the minimum < y < maximum check (cone.rs:119-127), so a truncated cone inside a group can be
+    hit at a time outside the interval in which the ray is inside the group's box.  The group is
+    still entered whenever the ray's line meets the box (group.rs:139), so that hit must win over a
+    farther one found earlier, even though the box lies entirely behind it."""
+    def world(o):
+        M = o.Matrix
+        flat = lambda c: o.Phong(o.Solid(o.Color(*c)), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0)
+        g = o.Group()
+        g.add_child(o.Cone(M.identity(), flat((0.9, 0.1, 0.1)), True, -1.0, 0.0, False))
+        # a wall between the early wall intersection and the box: it is hit first in scene order
+        wall = o.Plane(M.translation(0, 0, -1.5) * M.rotation_x(math.pi / 2), flat((0.1, 0.1, 0.9)), True)
+        return o.World([wall, g], [o.PointLight(o.point(-10, 10, -10), o.Color.white())])
+    d = (0.0, SQRT_2 / 2, SQRT_2 / 2)
+    rays = [((0.0, -4.5, -5.0), d), ((0.1, -4.5, -5.0), d), ((0.0, -4.4, -5.0), d)]
+    got = both(host, orc, world, rays, remaining=0)
+    assert np.abs(got[0] - (0.9, 0.1, 0.1)).max() <= 1e-12   # the cone's unchecked intersection at t = 3.36
+    for sign in (1.0, -1.0):  # and from the other side, where the box is ahead and the hit behind
+        o = np.array(rays[0][0]) + sign * 20.0 * np.array(d)
+        both(host, orc, world, [(tuple(o), tuple(-sign * np.array(d)))], remaining=0)
 
 
 def test_rays_through_group_box_edges(host, orc):

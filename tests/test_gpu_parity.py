@@ -40,6 +40,7 @@ def check(img, ref, tol=1e-11):
     ("csg", (200, 120)),
     ("dragon", (160, 96)),
     ("teapot", (240, 160)),
+    ("field", (192, 108)),
 ])
 def test_render_matches_oracle(host, orc, name, size):
     W, H = size

@@ -6,7 +6,7 @@ for v in "$@"; do
   cp variants/$v.so raytracer_amd/csrc/librt_amd.so
   echo "== $v"
   timeout -k 10 120 python bench.py --no-cpu-baseline --steps 20 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('default4k', round(d['kernel_ms'],3), round(d['value']))"
-  for w in glass smooth_teapot dragon; do
+  for w in glass csg field teapot smooth_teapot dragon; do
     timeout -k 10 120 python bench.py --no-cpu-baseline --steps 10 --workload $w --width 1920 --height 1080 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$w', round(d['kernel_ms'],3), round(d['value']))"
   done
 done
