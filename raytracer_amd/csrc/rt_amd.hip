@@ -1893,6 +1893,9 @@ struct RecordBuilder {
     int best_split(const std::vector<int>& sib, int lo, int hi) {
         const int n = hi - lo;
         if (n <= 2) return lo + n / 2;
+        // Very long runs (an undivided mesh) are cut in their middle half, which bounds the work
+        // at n log n; short ones may peel off a single member.
+        const int edge = n > 1024 ? n / 4 : 1;
         suffix_area.assign(n + 1, 0.0);
         double mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
         for (int k = n - 1; k >= 1; --k) {
@@ -1905,7 +1908,7 @@ struct RecordBuilder {
         for (int k = 1; k < n; ++k) {
             grow(pmn, pmx, box[sib[lo + k - 1]]);
             const double cost = area(pmn, pmx) * k + suffix_area[k] * (n - k);
-            if (cost < best_cost) {
+            if (k >= edge && k <= n - edge && cost < best_cost) {
                 best_cost = cost;
                 best = lo + k;
             }

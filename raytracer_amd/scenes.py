@@ -149,7 +149,7 @@ OBJ_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
                        "obj")
 
 
-def mesh_world(api, variant="teapot", obj_dir=OBJ_DIR):
+def mesh_world(api, variant="teapot", obj_dir=OBJ_DIR, divide=True):
     """An OBJ mesh (the reference's tests/obj_files fixtures) parsed like
     src/scene/obj_file_parser.rs does, grouped, `divide(1)` (as src/lib.rs:308 does for its group),
     over a floor plane with one light.  Variants: teapot (flat triangles), smooth_teapot (smooth
@@ -163,7 +163,8 @@ def mesh_world(api, variant="teapot", obj_dir=OBJ_DIR):
     parser = api.ObjFileParser.parse_obj_file(os.path.join(obj_dir, variant + ".obj"), M.identity(),
                                               mat, True)
     group = parser.obj_to_group(t)
-    group.divide(1)
+    if divide:
+        group.divide(1)
     floor = api.Plane(M.translation(0.0, -0.2, 0.0), Phong.default(), True)
     lights = [api.PointLight(api.point(-10.0, 10.0, -10.0), Color.white())]
     return api.World([floor, group], lights)

@@ -51,6 +51,16 @@ def test_render_matches_oracle(host, orc, name, size):
     print(name, size, "max err", err, "8-bit diffs", bad)
 
 
+def test_undivided_mesh(host, orc):
+    """All 6320 teapot triangles as direct children of one group (no `divide`): the reference tests
+    every one of them against every ray that meets the group's box; the device walks nested boxes
+    over the run, which must not change a pixel."""
+    W, H = 80, 48
+    img = host.render(scenes.mesh_world(host, "teapot", divide=False), scenes.mesh_camera(host, W, H))
+    ref = orc.render(scenes.mesh_world(orc, "teapot", divide=False), scenes.mesh_camera(orc, W, H))
+    check(img, ref)
+
+
 def test_ppm_bytes_match(host, orc):
     W, H = 120, 80
     mw, mc = scenes.WORKLOADS["default"]
