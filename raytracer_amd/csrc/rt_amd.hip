@@ -949,11 +949,12 @@ DI void primary_ray(const DevJob& J, int px, int py, V3& ro, V3& rd) {
 // does; if the expensive tiles (deep reflection / refraction recursion) come last the GPU drains
 // while a few long wavefronts finish.  A pre-pass traces the centre ray of every tile and puts
 // the tile in a cost class by what that ray hits (2 transparent, 1 reflective, 0 neither or
-// nothing); the render kernel then takes the tiles class 2 first.  This only permutes the order
-// in which tiles are rendered.
+// nothing); a tile then takes the highest class among itself and its eight neighbours (the centre
+// of a tile at the edge of a mirror sees the background, but some of its pixels do not: such a tile
+// started among the last ones is what the whole frame then waits for).  The render kernel takes the
+// tiles class 2 first.  This only permutes the order in which tiles are rendered.
 template <bool XF, bool CULL, bool CSGM>
-__global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, long long n_tiles, int* __restrict__ order,
-                                                        unsigned long long* __restrict__ class_count) {
+__global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, long long n_tiles, int* __restrict__ tile_class) {
     const int lane = threadIdx.x;
     const long long tile = (long long)blockIdx.x * 64 + lane;
     const bool active = tile < n_tiles;
@@ -971,19 +972,56 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
         const RT_CONST SRec* sr = S.shade + h.node;
         cls = sr->transp != 0.0 ? 2 : (sr->refl != 0.0 ? 1 : 0);
     }
-    // order holds one array of n_tiles entries per class; one atomic per wavefront and class, the
-    // lanes of a class take consecutive positions
+    if (active) tile_class[tile] = cls;
+}
+
+// One tile per thread, ORDER_BLOCK tiles per workgroup.  The workgroup adds up its tiles per class
+// and takes its share of each class's array with one atomic per class (one atomic per wavefront
+// serialised two thousand of them on three words and took longer than the classification).
+constexpr int ORDER_BLOCK = 1024;
+__global__ void __launch_bounds__(ORDER_BLOCK) tile_order_kernel(int tiles_x, int tile_rows, long long n_tiles,
+                                                                 const int* __restrict__ tile_class, int* __restrict__ order,
+                                                                 unsigned long long* __restrict__ class_count) {
+    __shared__ unsigned long long base[ORDER_BLOCK / 64][3];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long tile = (long long)blockIdx.x * ORDER_BLOCK + threadIdx.x;
+    const bool active = tile < n_tiles;
+    int cls = 0;
+    if (active) {
+        const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int x = tx + dx, y = ty + dy;
+                if (x >= 0 && x < tiles_x && y >= 0 && y < tile_rows) {
+                    const int c = tile_class[(long long)y * tiles_x + x];
+                    cls = c > cls ? c : cls;
+                }
+            }
+        cls = cls < 0 ? 0 : (cls > 2 ? 2 : cls);
+    }
+    unsigned long long mine = 0ull;  // lanes of this wavefront in this lane's class
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         const unsigned long long mask = __ballot(active && cls == c);
-        if (mask != 0ull) {
-            const int leader = (int)__builtin_ctzll(mask);
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(&class_count[c], (unsigned long long)__builtin_popcountll(mask));
-            base = (unsigned long long)__shfl((long long)base, leader, 64);
-            const long long pos = (long long)base + __builtin_popcountll(mask & ((1ull << lane) - 1ull));
-            if (active && cls == c && pos < n_tiles) order[(long long)c * n_tiles + pos] = (int)tile;
+        if (lane == 0) base[wave][c] = (unsigned long long)__builtin_popcountll(mask);
+        if (cls == c) mine = mask;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int c = threadIdx.x;
+        unsigned long long total = 0ull;
+        for (int w = 0; w < ORDER_BLOCK / 64; ++w) total += base[w][c];
+        unsigned long long at = total ? atomicAdd(&class_count[c], total) : 0ull;
+        for (int w = 0; w < ORDER_BLOCK / 64; ++w) {  // counts become starting positions
+            const unsigned long long n = base[w][c];
+            base[w][c] = at;
+            at += n;
         }
+    }
+    __syncthreads();
+    if (active) {
+        const long long pos = (long long)base[wave][cls] + __builtin_popcountll(mine & ((1ull << lane) - 1ull));
+        if (pos >= 0 && pos < n_tiles) order[(long long)cls * n_tiles + pos] = (int)tile;
     }
 }
 
@@ -2156,7 +2194,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
             if (s->d_order) HIP_TRY(hipFree(s->d_order));
             s->d_order = nullptr;
             s->order_cap = 0;
-            HIP_TRY(hipMalloc((void**)&s->d_order, 3 * (size_t)tiles * sizeof(int)));
+            HIP_TRY(hipMalloc((void**)&s->d_order, 4 * (size_t)tiles * sizeof(int)));  // three order arrays and the classes
             s->order_cap = tiles;
         }
         job.tile_order = s->d_order;
@@ -2166,12 +2204,15 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
     if (job.tile_order) {
         DevJob pre = job;
         pre.tile_order = nullptr;
-        using Pre = void (*)(DevScene, DevJob, long long, int*, unsigned long long*);
+        using Pre = void (*)(DevScene, DevJob, long long, int*);
         static const Pre pres[4] = {tile_class_kernel<false, false, false>, tile_class_kernel<false, true, false>,
                                     tile_class_kernel<true, false, false>, tile_class_kernel<true, true, false>};
         Pre prek = s->any_csg ? tile_class_kernel<true, true, true> : pres[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
-        hipLaunchKernelGGL(prek, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, s->dev, pre, tiles, s->d_order,
-                           mine + COUNTER_WORDS);
+        int* classes = s->d_order + 3 * tiles;
+        hipLaunchKernelGGL(prek, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, s->dev, pre, tiles, classes);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)((tiles + ORDER_BLOCK - 1) / ORDER_BLOCK)), dim3(ORDER_BLOCK), 0, stream, job.tiles_x,
+                           job.local_tile_rows, tiles, (const int*)classes, s->d_order, mine + COUNTER_WORDS);
         HIP_TRY(hipGetLastError());
     }
     if (blocks > 0) {
