@@ -262,18 +262,20 @@ DI V3 reciprocal(V3 d) { return mk(reciprocal1(d.x), reciprocal1(d.y), reciproca
 // differ from the box times of its group by rounding.  Times are at most about
 // (|origin| + extent) / |direction| and carry a few ulps of that; cancellation in the quadratics
 // adds a term that grows with |origin|^2.  base = 1 + extent of the group boxes.
-DI double prune_margin(double base, double origin_sq, V3 rcp_dir) {
-    double r = fmax(fmax(fabs(rcp_dir.x), fabs(rcp_dir.y)), fabs(rcp_dir.z));  // NaN components are ignored
-    double m = (1e-9 * (base + origin_sq)) * r;
+DI double largest_abs(V3 v) { return fmax(fmax(fabs(v.x), fabs(v.y)), fabs(v.z)); }  // NaN components are ignored
+DI double prune_margin(double base, double origin_sq, double largest_rcp_dir) {
+    double m = (1e-9 * (base + origin_sq)) * largest_rcp_dir;
     return (m == m) ? m : INFINITY;  // no finite reciprocal at all: never prune
 }
-// The slab times through the reciprocals without the correction step of div_by: each is within
-// 1.5 ulp of the exact quotient, which decides tmin > tmax unless the two are that close.
-DI void slabs_near(V3 o, V3 y, double x0, double y0, double z0, double x1, double y1, double z1, double& tmin,
+// Approximate slab times as one FMA each: plane * (1/d) + (-origin/d), with y = 1/d correctly
+// rounded and n = -(origin * y) rounded once.  Each differs from the reference's quotient
+// (plane - origin) / d by at most about 3 eps (|plane| + |origin|) |y|.  Good enough to cull, and to
+// decide tmin > tmax unless the two are that close.  NaN (parallel) axes drop out of min / max.
+DI void slabs_near(V3 y, V3 n, double x0, double y0, double z0, double x1, double y1, double z1, double& tmin,
                    double& tmax) {
-    double ax = (x0 - o.x) * y.x, bx = (x1 - o.x) * y.x;
-    double ay = (y0 - o.y) * y.y, by = (y1 - o.y) * y.y;
-    double az = (z0 - o.z) * y.z, bz = (z1 - o.z) * y.z;
+    double ax = __builtin_fma(x0, y.x, n.x), bx = __builtin_fma(x1, y.x, n.x);
+    double ay = __builtin_fma(y0, y.y, n.y), by = __builtin_fma(y1, y.y, n.y);
+    double az = __builtin_fma(z0, y.z, n.z), bz = __builtin_fma(z1, y.z, n.z);
     tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
     tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
 }
@@ -375,10 +377,21 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     int i = 0;
     int cur_ctx = -1;
     V3 co = wo, cd = wd;  // the ray in the space of the transformed group `cur_ctx`
-    V3 cy = reciprocal(cd);  // exact reciprocals of cd, used by the fast slab test
-    double coo = dot(co, co);   // scales the padding of T_CULL boxes
-    double tpad = prune_margin(S.prune_base, coo, cy);
-    bool cfin = all_axes_finite(cd);
+    V3 cy, cn;         // exact reciprocals of cd (NaN where the reference treats the axis as parallel), and -co * cy
+                       // (with transformed groups cn and cym are formed at each use instead: registers are scarcer there)
+    double coo, cym;   // |co|^2 scales the padding of T_CULL boxes; cym = largest |cy|
+    double tpad;       // see prune_margin
+    bool cfin;
+    auto ray_changed = [&]() {
+        cy = reciprocal(cd);
+        if (!XF) cn = mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z));
+        coo = dot(co, co);
+        const double m = largest_abs(cy);
+        if (!XF) cym = m;
+        tpad = prune_margin(S.prune_base, coo, m);
+        cfin = all_axes_finite(cd);
+    };
+    ray_changed();
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
     int csg_depth = 0;  // open CSG shapes around the current record (wave-uniform)
     CsgList cl;
@@ -455,10 +468,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             co = wo;
             cd = wd;
             chain_ray(S, ctx, co, cd);
-            cy = reciprocal(cd);
-            coo = dot(co, co);
-            tpad = prune_margin(S.prune_base, coo, cy);
-            cfin = all_axes_finite(cd);
+            ray_changed();
             cur_ctx = ctx;
         }
         const bool act = i >= skip_until;
@@ -468,10 +478,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             V3 to = xpoint(q, co), td = xvec(q, cd);
             co = to;
             cd = td;
-            cy = reciprocal(cd);
-            coo = dot(co, co);
-            tpad = prune_margin(S.prune_base, coo, cy);
-            cfin = all_axes_finite(cd);
+            ray_changed();
             cur_ctx = i;
             i = i + 1;
             continue;
@@ -480,14 +487,14 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // Box p[0..5] grown by r0 + r1 * |origin|^2: r0 covers the rounding of this test, the
             // second term the rounding of the leaf's own quadratic for far-away origins (its
             // discriminant loses about eps * |origin|^2, which can turn a near miss into a hit).
-            // NaN times (zero direction components) leave their axis unconstrained.
-            const double pad = __builtin_fma(r1, coo, r0);
-            const V3 om = mk(co.x + pad, co.y + pad, co.z + pad), op = mk(co.x - pad, co.y - pad, co.z - pad);
-            double ax = (q[0] - om.x) * cy.x, bx = (q[3] - op.x) * cy.x;
-            double ay = (q[1] - om.y) * cy.y, by = (q[4] - op.y) * cy.y;
-            double az = (q[2] - om.z) * cy.z, bz = (q[5] - op.z) * cy.z;
-            double tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-            double tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+            // The growth is applied to the times: moving a plane by pad moves its time by at most
+            // pad * cym.  NaN times (parallel axes) leave their axis unconstrained.
+            const double padt = __builtin_fma(r1, coo, r0) * (XF ? largest_abs(cy) : cym);
+            double tmin, tmax;
+            slabs_near(cy, XF ? mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z)) : cn, q[0], q[1], q[2], q[3], q[4], q[5],
+                       tmin, tmax);
+            tmin -= padt;
+            tmax += padt;
             bool keep = !(tmin > tmax);
             if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
                 if (!TRACK) keep = keep && !(tmax < 0.0);                     // only positive times count
@@ -568,10 +575,13 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // bounds test in the shape's own space.
             double tmin, tmax;
             if (S.finite_bounds && __ballot(act && !cfin) == 0ull) {
-                // The uncorrected quotients decide almost every lane; the exact ones are only
-                // computed when some lane's tmin and tmax are within a few ulps of each other.
-                slabs_near(co, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
-                const bool close = fabs(tmax - tmin) <= 2e-15 * (fabs(tmin) + fabs(tmax));
+                // The approximate times decide almost every lane; the exact quotients are only
+                // computed when some lane's tmin and tmax are closer than the approximation is
+                // good for: both carry up to 3 eps (extent + |origin|) cym, and
+                // 6 eps (e + o) <= 4e-15 (1 + e + o^2) = 4e-6 tpad / cym for all e, o >= 0.
+                slabs_near(cy, XF ? mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z)) : cn, q[0], q[1], q[2], q[3], q[4],
+                           q[5], tmin, tmax);
+                const bool close = !(fabs(tmax - tmin) > 4e-6 * tpad);
                 if (__ballot(act && close) != 0ull)
                     slabs_fast(co, cd, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
             } else {
