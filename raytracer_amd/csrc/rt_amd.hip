@@ -283,8 +283,7 @@ DI void slabs_near(V3 y, V3 n, double x0, double y0, double z0, double x1, doubl
 // Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
 // for the n1/n2 bookkeeping, the parity and the latest of the leaf's non-positive times.
 struct LeafAcc {
-    double best;
-    bool found;
+    double best;  // 0.0: none yet (the times that count are > 0)
     int par;
     double negmax;
 };
@@ -306,10 +305,7 @@ DI long long total_key(double v) {
 template <bool CONTAINERS>
 DI void leaf_count(LeafAcc& a, double t) {
     if (!CONTAINERS) {
-        if (t > 0.0 && (!a.found || t < a.best)) {
-            a.best = t;
-            a.found = true;
-        }
+        if (t > 0.0 && (a.best == 0.0 || t < a.best)) a.best = t;
     } else if (t <= 0.0) {
         a.par ^= 1;
         a.negmax = fmax(a.negmax, t);
@@ -358,7 +354,7 @@ template <int MODE, bool XF, bool CULL, bool CSGM>
 DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
     constexpr bool TRACK = MODE == MODE_CONTAINERS;
     if (!TRACK) {
-        h.found = false;
+        h.found = false;  // inside the walk "found" is h.node >= 0; the flag is set at the end
         h.t = 0.0;
         h.node = -1;
     }
@@ -403,7 +399,6 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     // time (group.rs:147, world.rs:65).
     auto begin_leaf = [&](int node) {
         acc.best = 0.0;
-        acc.found = false;
         acc.par = 0;
         acc.negmax = -INFINITY;
         acc_node = node;
@@ -423,8 +418,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     // being copied around the join points of every leaf visit.
     auto commit_leaf = [&]() {
         if (!TRACK) {
-            const bool better = acc.found && (!h.found || acc.best < h.t);
-            h.found = h.found || acc.found;
+            const bool better = acc.best != 0.0 && (h.node < 0 || acc.best < h.t);
             h.t = better ? acc.best : h.t;
             h.node = better ? acc_node : h.node;
         } else {
@@ -437,7 +431,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             h.a_t = first ? acc.negmax : h.a_t;
             h.a_id = first ? acc_node : h.a_id;
         }
-        if (early && h.found && h.t < limit) skip_until = INT_MAX;  // this lane is decided
+        if (early && h.node >= 0 && h.t < limit) skip_until = INT_MAX;  // this lane is decided
     };
 
 #ifdef RT_PROFILE
@@ -499,7 +493,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
                 if (!TRACK) keep = keep && !(tmax < 0.0);                     // only positive times count
                 if (MODE == MODE_SHADOW) keep = keep && !(tmin > limit);     // beyond the light
-                if (!TRACK) keep = keep && !(h.found && tmin > h.t);         // behind the nearest hit so far
+                if (!TRACK) keep = keep && !(h.node >= 0 && tmin > h.t);     // behind the nearest hit so far
                 if (TRACK) keep = keep && !(tmin > 0.0);                      // only times <= 0 count
             }
             keep = keep && act;
@@ -595,7 +589,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             if ((!CSGM || csg_depth == 0) && !(kind & T_LINE_ONLY)) {  // inside a CSG shape its filter needs every intersection
                 if (!TRACK) inside = inside && !(tmax < -tpad);
                 if (MODE == MODE_SHADOW) inside = inside && !(tmin > limit + tpad);
-                if (!TRACK) inside = inside && !(h.found && tmin > h.t + tpad);
+                if (!TRACK) inside = inside && !(h.node >= 0 && tmin > h.t + tpad);
                 if (TRACK) inside = inside && !(tmin > tpad);
             }
             if (act && !inside) skip_until = skip;
@@ -734,6 +728,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             i = wave_min(skip_until);  // INT_MAX when every lane is decided: the loop ends
         }
     }
+    if (!TRACK) h.found = h.node >= 0;
 }
 
 // Shape::normal_to_world (shape.rs:83-98): per level inverse-transpose, w := 0, normalise, then
