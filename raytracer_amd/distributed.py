@@ -33,10 +33,18 @@ class FrameGather:
         self.index = None
         if rank == dst:
             self.frame = torch.empty((height, width, 3), dtype=dtype, device=device)
-            self.parts = [None if r == dst else torch.empty((self.rows[r], width, 3), dtype=dtype, device=device)
-                          for r in range(world_size)]
+            # the peers' rows arrive in slices of one staging buffer, so that a single index_copy_
+            # puts them all in frame order (one launch per frame instead of one per peer)
+            others = [r for r in range(world_size) if r != dst]
+            self.staging = torch.empty((sum(self.rows[r] for r in others), width, 3), dtype=dtype, device=device)
+            self.parts = [None] * world_size
+            at = 0
+            for r in others:
+                self.parts[r] = self.staging[at: at + self.rows[r]]
+                at += self.rows[r]
             self.index = [torch.from_numpy(np.asarray(host.global_rows(height, r, world_size), dtype=np.int64)).to(device)
                           for r in range(world_size)]
+            self.index_others = torch.cat([self.index[r] for r in others]) if others else None
 
     def __call__(self, local):
         """local: this rank's (rows, W, 3) tensor.  Returns the full frame on rank dst."""
@@ -85,10 +93,10 @@ class FrameGather:
     def _place(self, local):
         if self.rank != self.dst:
             return None
-        for r in range(self.world_size):
-            part = local if r == self.dst else self.parts[r]
-            if self.rows[r] > 0:
-                self.frame.index_copy_(0, self.index[r], part)
+        if self.rows[self.dst] > 0:
+            self.frame.index_copy_(0, self.index[self.dst], local)
+        if self.index_others is not None and self.index_others.numel() > 0:
+            self.frame.index_copy_(0, self.index_others, self.staging)
         return self.frame
 
 
