@@ -367,6 +367,63 @@ def test_cone_in_group_hit_outside_its_box(host, orc):
         both(host, orc, world, [(tuple(o), tuple(-sign * np.array(d)))], remaining=0)
 
 
+def scattered(o, k):
+    """Small spheres far out on alternating sides, listed between the objects of interest, so that
+    sorting the world's objects in space pays and the device does not visit them in list order."""
+    M = o.Matrix
+    x = (10.0 + 2 * k) * (1 if k % 2 else -1)
+    return o.Sphere(M.translation(x, 6.0, 0.5 * k) * M.scaling(0.3, 0.3, 0.3),
+                    o.Phong(o.Solid(o.Color(0.5, 0.5, 0.5)), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0), True)
+
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_equal_times_go_to_the_first_object_in_list_order(host, orc, swap):
+    """Two cubes share the face x = 1 and axis-parallel rays meet it at exactly the same time in both
+    object spaces (t = 4).  Intersection::hit takes the first of equal times in the stable order of
+    World::intersect_world (world.rs:55-68), i.e. the object listed first, although the other cube's
+    box lies lower on every axis and a spatial ordering of the records visits it first."""
+    def world(o):
+        M = o.Matrix
+        flat = lambda c: o.Phong(o.Solid(o.Color(*c)), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0)
+        a = o.Cube(M.identity(), flat((0.9, 0.1, 0.1)), True)                                  # [-1, 1]^3
+        b = o.Cube(M.translation(-1, -1, -1) * M.scaling(2, 2, 2), flat((0.1, 0.1, 0.9)), True)  # [-3, 1]^3
+        first, second = (b, a) if swap else (a, b)
+        objects = [scattered(o, 0), first, scattered(o, 1), scattered(o, 2), second, scattered(o, 3), scattered(o, 4),
+                   scattered(o, 5)]
+        return o.World(objects, [o.PointLight(o.point(-10, 10, -10), o.Color.white())])
+    rng = np.random.default_rng(17)
+    rays = [((5.0, float(y), float(z)), (-1.0, 0.0, 0.0)) for y, z in rng.uniform(-0.99, 0.99, (200, 2))]
+    got = both(host, orc, world, rays, remaining=0)
+    want = (0.1, 0.1, 0.9) if swap else (0.9, 0.1, 0.1)
+    assert np.abs(got - want).max() <= 1e-12
+
+
+@pytest.mark.parametrize("swap", [False, True])
+def test_equal_times_in_the_container_walk(host, orc, swap):
+    """The same two cubes made of glass with different refractive indices.  A ray started inside both
+    has their two entries behind it at exactly the same time (t = -0.5), so n1 at the next surface
+    (world.rs:99-132) is the index of whichever cube the sorted list holds last: the one listed later
+    in the world.  A ray from outside meets both at t = 4 and enters the one listed first."""
+    def world(o):
+        M = o.Matrix
+
+        def glass(t, ri, c):
+            return o.Cube(t, o.Phong(o.Solid(o.Color(*c)), 0.1, 0.4, 0.3, 100.0, 0.2, 0.9, ri), True)
+        a = glass(M.identity(), 1.5, (0.4, 0.2, 0.2))
+        b = glass(M.translation(-1, -1, -1) * M.scaling(2, 2, 2), 2.0, (0.2, 0.4, 0.2))
+        first, second = (b, a) if swap else (a, b)
+        back = o.Plane(M.translation(-8, 0, 0) * M.rotation_z(math.pi / 2),
+                       o.Phong(o.Checker(None, None, M.scaling(0.5, 0.5, 0.5)), 1.0, 0.0, 0.0, 200.0, 0.0, 0.0, 1.0), True)
+        objects = [scattered(o, 0), first, scattered(o, 1), back, scattered(o, 2), second, scattered(o, 3), scattered(o, 4),
+                   scattered(o, 5)]
+        return o.World(objects, [o.PointLight(o.point(-5, 5, -8), o.Color.white())])
+    rng = np.random.default_rng(29)
+    rays = []
+    for x in (5.0, 0.5):
+        rays += [((x, float(y), float(z)), (-1.0, 0.0, 0.0)) for y, z in rng.uniform(-0.9, 0.9, (40, 2))]
+    both(host, orc, world, rays)
+
+
 def test_rays_through_group_box_edges(host, orc):
     """The group bounds test (group.rs:139, bounding_box.rs:80-98) decides by tmin > tmax.  The device
     first compares uncorrected quotients and only falls back to the exact ones when they are within
