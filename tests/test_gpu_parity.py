@@ -61,6 +61,40 @@ def test_undivided_mesh(host, orc):
     check(img, ref)
 
 
+def test_many_loose_triangles(host, orc):
+    """20 000 small triangles in random order as direct children of one group and 300 more directly in
+    the world: runs long enough for every path of the record builder (sorted cuts, the widest-axis
+    cut of very long runs).  The reference tests each of them against every ray."""
+    import time
+    rng = np.random.default_rng(41)
+    centres = rng.uniform(-4, 4, (20300, 3))
+    offs = rng.uniform(-0.15, 0.15, (20300, 3, 3))
+
+    def world(api):
+        mat = api.Phong(api.Solid(api.Color(0.7, 0.5, 0.3)), 0.2, 0.7, 0.2, 50.0, 0.1, 0.0, 1.0)
+        g = api.Group()
+        loose = []
+        for k in range(20300):
+            pts = [api.point(*(centres[k] + offs[k, j])) for j in range(3)]
+            t = api.Triangle(*pts, None, mat, True)
+            if k < 20000:
+                g.add_child(t)
+            else:
+                loose.append(t)
+        return api.World([g] + loose, [api.PointLight(api.point(-10, 10, -10), api.Color.white())])
+    n = 1200
+    o = np.tile(np.array([0.0, 1.0, -12.0]), (n, 1))
+    d = np.array([0.0, -0.08, 1.0]) + rng.uniform(-0.3, 0.3, (n, 3))
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    t0 = time.time()
+    got = host.color_at(world(host), o, d, remaining=2)
+    seconds = time.time() - t0
+    ref = orc.color_at_batch(world(orc), o, d, remaining=2)
+    assert np.abs(got - ref).max() <= 1e-11
+    assert (ref != 0).any(axis=1).mean() > 0.3
+    assert seconds < 60.0, "scene build + %d rays took %.1f s" % (n, seconds)
+
+
 def test_ppm_bytes_match(host, orc):
     W, H = 120, 80
     mw, mc = scenes.WORKLOADS["default"]
