@@ -6,7 +6,7 @@
 //     wavefront per workgroup; no barriers, no matrix cores: the path has no dense contraction, it
 //     is scalar f64 arithmetic per ray.  LDS only holds finished pixels until the tile is stored.
 //   * scene traversal is wave-synchronous: the wavefront walks an array of 128-byte traversal
-//     records (TRec, the node table in pre-order) with ONE uniform index.  Records are therefore
+//     records (TRec, the node table depth first) with ONE uniform index.  Records are therefore
 //     fetched with scalar loads (constant address space) into SGPRs and cost no vector registers or
 //     vector memory traffic.  Each lane only keeps the index up to which it is masked off
 //     (`skip_until`), set when its ray misses a group's bounding box; when a wave-wide ballot
@@ -50,16 +50,20 @@
 namespace {
 
 // Traversal record: everything one step of the scene walk needs, in one 128-byte line, so that a
-// step costs a single scalar-load round trip.  Records follow the pre-order of the node table; a
-// node whose transform is not the identity AND which carries its own payload (a transformed group
-// or triangle) is preceded by an extra T_XFORM record that holds its inverse.
-// A finite sphere, cube or cylinder leaf is preceded by a T_CULL record: a padded box
-// around the leaf in the space its ray arrives in.  Lanes whose ray cannot reach the box skip
-// the leaf; this never changes a result, it only avoids arithmetic whose outcome is "no hit".
+// step costs a single scalar-load round trip.  Records follow the depth-first order of the node
+// table, except that the boxed children of one group may be sorted in space (the walk breaks ties
+// between equal times by node index, so their order does not show); a node whose transform is not
+// the identity AND which carries its own payload (a transformed group or triangle) is preceded by
+// an extra T_XFORM record that holds its inverse.
+// T_CULL records hold a padded box in the space the ray arrives in, in front of a finite sphere,
+// cube or cylinder leaf or of a set of siblings (`skip` = the first record after what the box
+// covers).  Lanes whose ray cannot reach the box skip that part; this never changes a result, it
+// only avoids arithmetic whose outcome is "no hit".
 // A CSG shape (csg.rs) is bracketed by T_CSG_BEGIN (its box, tested like a group's; `skip` = the
 // record after the matching end record) and T_CSG_END (`node` = the CSG node, `skip` = the NODE
-// index where its right operand starts, the operation in bits 12-13).  Between them the leaves collect their intersections per lane instead
-// of competing for the nearest hit; the end record sorts and filters them.
+// index where its right operand starts, the operation in bits 12-13).  Between them the leaves
+// collect their intersections per lane instead of competing for the nearest hit; the end record
+// sorts and filters them.
 enum { T_XFORM = 8, T_CULL = 9, T_CSG_BEGIN = 10, T_CSG_END = 11, T_HAS_INV = 0x100, T_CLOSED = 0x200,
        T_OWN_XFORM = 0x400, T_LINE_ONLY = 0x800, T_CSG_OP_SHIFT = 12 };
 struct alignas(16) TRec {
