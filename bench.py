@@ -89,8 +89,8 @@ def load_traffic(workload, W, H):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)  # a frame is under a millisecond; the first few dozen run before the clocks settle
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="default")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
