@@ -101,6 +101,11 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
     ap.add_argument("--gather-mode", choices=["p2p", "collective"], default="p2p",
                     help="N > 1: grouped send/recv of exactly each rank's rows (default) or one padded dist.gather")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=0,
+                    help="frames rendering at once: 2 = consecutive frames on two streams (each with its own scene "
+                         "handle and buffer), so that the next frame's wavefronts fill the GPU while the long wavefronts "
+                         "of this one finish.  Default: 1 on one GPU, 2 on several (a rank's share of the frame is then "
+                         "not much longer than its longest wavefront)")
     args = ap.parse_args()
 
     import torch
@@ -130,22 +135,28 @@ def main():
     W = args.width or (3840 if world_size == 1 else 7680)
     H = args.height or (2160 if world_size == 1 else 4320)
 
+    in_flight = args.in_flight or (2 if world_size > 1 and not args.no_overlap else 1)
     host = api.load()
     make_world, make_camera = scenes.WORKLOADS[args.workload]
-    world, cam = make_world(host), make_camera(host, W, H)
-    scene = host.scene_handle(world, device=local_rank)
+    # one scene handle per frame in flight: launches on one handle must be stream-ordered
+    worlds = [make_world(host) for _ in range(in_flight)]
+    world, cam = worlds[0], make_camera(host, W, H)
+    scenes_h = [host.scene_handle(w, device=local_rank) for w in worlds]
+    scene = scenes_h[0]
     rows = host.local_rows(H, rank, world_size)
     u8 = world_size > 1 and args.gather == "u8"
     dtype = torch.uint8 if u8 else torch.float64
-    buffers = [torch.empty((rows, W, 3), dtype=dtype, device=dev) for _ in range(2 if world_size > 1 else 1)]
+    buffers = [torch.empty((rows, W, 3), dtype=dtype, device=dev) for _ in range(2 if world_size > 1 or in_flight > 1 else 1)]
 
     from raytracer_amd.distributed import FrameGather, OverlappedGather
     gather = FrameGather(host, W, H, rank, world_size, dev, dtype=dtype, mode=args.gather_mode) if world_size > 1 else None
-    pipe = OverlappedGather(gather, buffers) if gather is not None and not args.no_overlap else None
+    render_streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if in_flight > 1 else None
+    pipe = (OverlappedGather(gather, buffers, render_streams)
+            if (gather is not None and not args.no_overlap) or in_flight > 1 else None)
 
-    def render(buf):
+    def render(buf, slot=0):
         stream = torch.cuda.current_stream().cuda_stream
-        host.render_device(world, cam, buf.data_ptr(), stream=stream, device=local_rank, rank=rank,
+        host.render_device(worlds[slot % in_flight], cam, buf.data_ptr(), stream=stream, device=local_rank, rank=rank,
                            world_size=world_size, max_depth=args.max_depth, u8=u8)
 
     def step():
@@ -174,7 +185,7 @@ def main():
     # kernel device times of the timed launches, from HIP events on the launch stream
     cap = min(args.steps, 256)
     ms = (ctypes.c_float * cap)()
-    got = host.abi.rt_scene_launch_times(scene, ms, cap)
+    got = host.abi.rt_scene_launch_times(scene, ms, min(cap, max(args.steps // in_flight, 1)))
     kernel_ms = sum(ms[i] for i in range(got)) / max(got, 1)
     st = abi.rt_stats()
     host.abi.rt_scene_ray_counts(scene, ctypes.byref(st))
@@ -215,13 +226,17 @@ def main():
                     world_size,
                     ", RCCL gather of %s rows to rank 0%s" % (
                         "clamped u8" if u8 else "f64", "" if args.no_overlap else ", overlapped with the next frame's render")
-                    if world_size > 1 else ""),
+                    if world_size > 1 else "") + (", %d frames in flight on separate streams" % in_flight if in_flight > 1 else ""),
             },
-            "kernel_ms": kernel_ms,
+            "kernel_ms": kernel_ms,  # mean launch duration; with 2 frames in flight launches overlap and each takes longer
+            "frames_in_flight": in_flight,
         }
         if work is not None:
             flops = float(work["flops"])
-            achieved = flops / world_size / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+            # with two frames in flight a launch shares the GPU with its neighbour for most of its life:
+            # the rate is then what the GPU sustains over the timed region, not flops / one launch's duration
+            per_frame_ms = ms_per_step if in_flight > 1 else kernel_ms
+            achieved = flops / world_size / (per_frame_ms * 1e-3) / 1e12 if per_frame_ms > 0 else 0.0
             out["roofline"] = {
                 "bound": "valu-fp64",
                 "achieved": achieved,
@@ -240,8 +255,8 @@ def main():
             out["roofline"]["hbm"] = {
                 "peak_gbs": HBM_PEAK_GBS,
                 "algorithmic_bytes_per_launch": frame_bytes,
-                "algorithmic_gbs": frame_bytes / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
-                "measured_gbs": traffic / (kernel_ms * 1e-3) / 1e9 if traffic and kernel_ms > 0 else None,
+                "algorithmic_gbs": frame_bytes / (per_frame_ms * 1e-3) / 1e9 if per_frame_ms > 0 else 0.0,
+                "measured_gbs": traffic / (per_frame_ms * 1e-3) / 1e9 if traffic and per_frame_ms > 0 else None,
             }
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload, W, H)

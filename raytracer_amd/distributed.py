@@ -101,32 +101,42 @@ class FrameGather:
 
 
 class OverlappedGather:
-    """Double-buffered frames: the exchange of frame k runs on a side stream while the caller's
-    stream renders frame k + 1 into the other buffer.  On CPU tensors (tests) it degrades to render
-    then gather.  The frame returned by step() is complete once `wait()` has returned."""
+    """Double-buffered frames: the exchange of frame k runs on a side stream while frame k + 1 renders
+    into the other buffer.  With `render_streams` (one per buffer) consecutive frames also render on
+    different streams, so the wavefronts of frame k + 1 fill the GPU while the last long wavefronts
+    of frame k finish; each buffer then needs its own scene handle, because launches on one scene
+    must be stream-ordered.  On CPU tensors (tests) it degrades to render then gather.  The frame
+    returned by step() is complete once `wait()` has returned."""
 
-    def __init__(self, gather, buffers):
+    def __init__(self, gather, buffers, render_streams=None):
         assert len(buffers) >= 2
         self.gather, self.buffers, self.k = gather, buffers, 0
         self.cuda = buffers[0].is_cuda
+        self.render_streams = render_streams
         if self.cuda:
+            assert render_streams is None or len(render_streams) == len(buffers)
             self.side = torch.cuda.Stream(device=buffers[0].device)
             self.done = [None] * len(buffers)
 
     def step(self, render):
-        """render(buffer) enqueues the render of the next frame into `buffer` on the current stream."""
+        """render(buffer, slot) enqueues the render of the next frame into `buffer` on the current
+        stream; `slot` is the buffer's index."""
         b = self.k % len(self.buffers)
         self.k += 1
         buf = self.buffers[b]
         if not self.cuda:
-            render(buf)
-            return self.gather(buf)
-        main = torch.cuda.current_stream(buf.device)
-        if self.done[b] is not None:
-            main.wait_event(self.done[b])  # the exchange that last read this buffer
-        render(buf)
-        ready = torch.cuda.Event()
-        ready.record(main)
+            render(buf, b)
+            return self.gather(buf) if self.gather is not None else buf
+        stream = self.render_streams[b] if self.render_streams else torch.cuda.current_stream(buf.device)
+        with torch.cuda.stream(stream):
+            if self.done[b] is not None:
+                stream.wait_event(self.done[b])  # the exchange that last read this buffer
+            render(buf, b)
+            ready = torch.cuda.Event()
+            ready.record(stream)
+        if self.gather is None:
+            self.done[b] = ready
+            return buf
         with torch.cuda.stream(self.side):
             self.side.wait_event(ready)
             frame = self.gather(buf)
@@ -136,4 +146,4 @@ class OverlappedGather:
 
     def wait(self):
         if self.cuda:
-            self.side.synchronize()
+            torch.cuda.synchronize(self.buffers[0].device)

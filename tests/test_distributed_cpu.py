@@ -75,7 +75,7 @@ def _worker_u8(rank, world_size, port, W, H, out_path, mode="p2p"):
         pipe = OverlappedGather(gather, bufs)
         frames = []
         for k in range(3):
-            def render(buf, k=k):
+            def render(buf, slot, k=k):
                 # pixel (x, y, c) of frame k is a fixed function of its frame coordinates
                 yy = torch.from_numpy(rows).view(-1, 1, 1)
                 xx = torch.arange(W).view(1, -1, 1)

@@ -91,3 +91,31 @@ def test_other_workloads_1920x1080(host, orc, name):
     assert (quantise(got) != quantise(ref)).sum() == 0
     img8 = host.render_u8(mw(host), mc(host, W, H))
     assert np.array_equal(img8, quantise(img).astype(np.uint8))
+
+
+def test_two_frames_in_flight(host):
+    """Consecutive frames on two streams, each with its own scene handle and buffer (what bench.py does
+    on several GPUs so that the next frame's wavefronts fill the GPU while this frame's longest ones
+    finish): every frame equals the same frame rendered alone."""
+    torch = pytest.importorskip("torch")
+    from raytracer_amd.distributed import OverlappedGather
+    W, H = 960, 540
+    dev = torch.device("cuda", 0)
+    mw, mc = scenes.WORKLOADS["default"]
+    worlds = [mw(host), mw(host)]
+    cams = [mc(host, W, H), scenes.glass_camera(host, W, H)]   # two different views of the scene
+    want = [host.render_u8(worlds[0], cam) for cam in cams]
+    buffers = [torch.empty((H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+    pipe = OverlappedGather(None, buffers, streams)
+    for pair in range(4):
+        order = [pair % 2, 1 - pair % 2]   # which view goes to which slot alternates
+
+        def render(buf, slot):
+            host.render_device(worlds[slot], cams[order[slot]], buf.data_ptr(),
+                               stream=torch.cuda.current_stream().cuda_stream, device=0, u8=True)
+        pipe.step(render)
+        pipe.step(render)
+        pipe.wait()
+        for slot in range(2):
+            assert np.array_equal(buffers[slot].cpu().numpy(), want[order[slot]]), (pair, slot)
