@@ -331,6 +331,10 @@ struct Hit {
 #endif
 };
 
+// Lanes of the wavefront for which the predicate holds, straight from the comparison's lane mask
+// (the library's __ballot takes an int, which costs a select and a second comparison).
+DI unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+
 DI int wave_min(int v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
@@ -370,7 +374,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
 #ifdef RT_PROFILE
     h.visits = 0;
 #endif
-    if (__ballot(active) == 0ull) return;
+    if (wave_ballot(active) == 0ull) return;
 
     int skip_until = active ? 0 : INT_MAX;
     const int n = S.n_trav;
@@ -505,7 +509,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             }
             keep = keep && act;
             if (act && !keep) skip_until = skip;
-            i = (__ballot(keep) == 0ull) ? skip : i + 1;
+            i = (wave_ballot(keep) == 0ull) ? skip : i + 1;
             continue;
         }
         if (CSGM && type == T_CSG_END) {
@@ -568,14 +572,14 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 cl.n = 0;
             }
             i = i + 1;
-            if (early && __ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
+            if (early && wave_ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
             continue;
         }
         if (type == RT_GROUP || (CSGM && type == T_CSG_BEGIN)) {
             // Group::local_intersect (group.rs:133-154) and CSG::local_intersect (csg.rs:145):
             // bounds test in the shape's own space.
             double tmin, tmax;
-            if (S.finite_bounds && __ballot(act && !cfin) == 0ull) {
+            if (S.finite_bounds && wave_ballot(act && !cfin) == 0ull) {
                 // The approximate times decide almost every lane; the exact quotients are only
                 // computed when some lane's tmin and tmax are closer than the approximation is
                 // good for: both carry up to 3 eps (extent + |origin|) cym, and
@@ -583,7 +587,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 slabs_near(cy, XF ? mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z)) : cn, q[0], q[1], q[2], q[3], q[4],
                            q[5], tmin, tmax);
                 const bool close = !(fabs(tmax - tmin) > 4e-6 * tpad);
-                if (__ballot(act && close) != 0ull)
+                if (wave_ballot(act && close) != 0ull)
                     slabs_fast(co, cd, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
             } else {
                 slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
@@ -600,7 +604,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 if (TRACK) inside = inside && !(tmin > tpad);
             }
             if (act && !inside) skip_until = skip;
-            const bool enter = __ballot(inside) != 0ull;
+            const bool enter = wave_ballot(inside) != 0ull;
             if (CSGM && type == T_CSG_BEGIN && enter) {
                 cl.start[csg_depth] = cl.n;
                 ++csg_depth;
@@ -636,7 +640,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 }
                 case RT_CUBE: {  // cube.rs:77-98
                     double tmin, tmax;
-                    if (__ballot(!all_axes_finite(ld)) == 0ull)
+                    if (wave_ballot(!all_axes_finite(ld)) == 0ull)
                         slabs_fast(lo, ld, reciprocal(ld), -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
                     else
                         slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
@@ -731,7 +735,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         // accumulator, and the hit state is not duplicated around the branch
         if (!CSGM || csg_depth == 0) commit_leaf();
         i = i + 1;
-        if (early && __ballot(i >= skip_until) == 0ull) {
+        if (early && wave_ballot(i >= skip_until) == 0ull) {
             i = wave_min(skip_until);  // INT_MAX when every lane is decided: the loop ends
         }
     }
@@ -1014,7 +1018,7 @@ __global__ void __launch_bounds__(ORDER_BLOCK) tile_order_kernel(int tiles_x, in
     unsigned long long mine = 0ull;  // lanes of this wavefront in this lane's class
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const unsigned long long mask = __ballot(active && cls == c);
+        const unsigned long long mask = wave_ballot(active && cls == c);
         if (lane == 0) base[wave][c] = (unsigned long long)__builtin_popcountll(mask);
         if (cls == c) mine = mask;
     }
@@ -1109,7 +1113,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
     unsigned long long prof_closest = 0, prof_shadow = 0, prof_visits = 0, prof_traces = 0, prof_rounds = 0;
     unsigned long long prof_prepare = 0, prof_light = 0, prof_return = 0;
 #endif
-    while (__ballot(pending) != 0ull) {
+    while (wave_ballot(pending) != 0ull) {
         Hit h;
 #ifdef RT_PROFILE
         unsigned long long pt = __builtin_amdgcn_s_memtime();
@@ -1119,7 +1123,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
             // n1/n2 (world.rs:99-132) are only read when the hit material is transparent
             // (world.rs:185, 243-246): only those lanes run the container pass.
             const bool need = pending && h.found && S.shade[h.node].transp != 0.0;
-            if (__ballot(need) != 0ull) trace<MODE_CONTAINERS, XF, CULL, CSGM>(S, need, ro, rd, 0.0, h);
+            if (wave_ballot(need) != 0ull) trace<MODE_CONTAINERS, XF, CULL, CSGM>(S, need, ro, rd, 0.0, h);
         }
 #ifdef RT_PROFILE
         prof_closest += __builtin_amdgcn_s_memtime() - pt;
@@ -1321,7 +1325,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
             prof_shadow += __builtin_amdgcn_s_memtime() - ps;
             prof_visits += sh.visits;
-            prof_traces += (__ballot(shadow_matters) != 0ull) ? 1 : 0;
+            prof_traces += (wave_ballot(shadow_matters) != 0ull) ? 1 : 0;
 #endif
             if (shade) {
                 ++n_shadow;
@@ -1433,7 +1437,7 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
         lane_pixel(J, wave, lane, px, local_y, lty);
         out_index = (long long)local_y * J.width + px;
     }
-    const bool whole_tile = J.wide_stores && __ballot(valid) == ~0ull;
+    const bool whole_tile = J.wide_stores && wave_ballot(valid) == ~0ull;
     if (J.out_u8) {
         // 24 bytes per tile row: the lanes' bytes are packed in LDS and 48 lanes store one dword each.
         __shared__ unsigned tile8_lds[RT_BLOCK_WAVES][48];
