@@ -298,12 +298,17 @@ struct CsgList {
     int n;
     int start[RT_MAX_CSG_NEST];  // list length when each open CSG shape began
 };
-// f64::total_cmp as an integer key (intersection.rs:60-64).
+// f64::total_cmp as an integer key (intersection.rs:60-64); the map is its own inverse.
 DI long long total_key(double v) {
     long long b = __double_as_longlong(v);
     b ^= (long long)((unsigned long long)(b >> 63) >> 1);
     return b;
 }
+DI double key_time(long long k) {
+    k ^= (long long)((unsigned long long)(k >> 63) >> 1);
+    return __longlong_as_double(k);
+}
+constexpr int CSG_FAST = 8;  // list parts up to this length are sorted in registers
 // CONTAINERS: only the times <= 0 are of interest (see MODE_CONTAINERS); otherwise only the nearest
 // positive time.
 template <bool CONTAINERS>
@@ -518,6 +523,93 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             --csg_depth;
             const int first = cl.start[csg_depth];
             const int last = cl.n < RT_MAX_CSG_HITS ? cl.n : RT_MAX_CSG_HITS;
+            if (wave_ballot(last - first > CSG_FAST) == 0ull) {
+                // Short lists (every lane's part has at most CSG_FAST entries: the usual case) are
+                // sorted and filtered in registers.  The list lives in scratch memory, where every
+                // step of an insertion sort is a load that depends on the one before it.
+                const int m = last - first;
+                long long key[CSG_FAST];
+                int id[CSG_FAST], pos[CSG_FAST];
+#pragma unroll
+                for (int k = 0; k < CSG_FAST; ++k) {
+                    const bool in = k < m;
+                    const int at = in ? first + k : 0;
+                    const double t = cl.t[at];
+                    id[k] = cl.id[at];
+                    key[k] = in ? total_key(t) : LLONG_MAX;
+                    pos[k] = k;  // arrival order: what a stable sort keeps among equal keys
+                }
+                // 19-comparator sorting network for 8 inputs; (key, arrival) pairs are all different,
+                // so the result is the stable order.
+                auto order = [&](int a, int b) {
+                    const bool swap = key[b] < key[a] || (key[b] == key[a] && pos[b] < pos[a]);
+                    const long long ka = key[a], kb = key[b];
+                    const int ia = id[a], ib = id[b], pa = pos[a], pb = pos[b];
+                    key[a] = swap ? kb : ka;
+                    key[b] = swap ? ka : kb;
+                    id[a] = swap ? ib : ia;
+                    id[b] = swap ? ia : ib;
+                    pos[a] = swap ? pb : pa;
+                    pos[b] = swap ? pa : pb;
+                };
+                static_assert(CSG_FAST == 8, "the network below sorts eight inputs");
+                order(0, 1); order(2, 3); order(4, 5); order(6, 7);
+                order(0, 2); order(1, 3); order(4, 6); order(5, 7);
+                order(1, 2); order(5, 6); order(0, 4); order(3, 7);
+                order(1, 5); order(2, 6);
+                order(1, 4); order(3, 6);
+                order(2, 4); order(3, 5);
+                order(3, 4);
+                const int op = (kind >> T_CSG_OP_SHIFT) & 3;
+                bool inl = false, inr = false;
+                bool keep[CSG_FAST];
+#pragma unroll
+                for (int a = 0; a < CSG_FAST; ++a) {
+                    const bool in = a < m;  // the padding sorts last
+                    const bool lhit = id[a] > rnode && id[a] < skip;  // the left operand's nodes (csg.rs:91)
+                    bool allowed;                                     // csg.rs:113-140
+                    if (op == 0)
+                        allowed = (lhit && !inr) || (!lhit && inl);
+                    else if (op == 1)
+                        allowed = (lhit && inr) || (!lhit && inl);
+                    else
+                        allowed = (lhit && !inr) || (!lhit && !inl);
+                    keep[a] = in && allowed;
+                    inl = inl != (in && lhit);
+                    inr = inr != (in && !lhit);
+                }
+                if (csg_depth == 0) {
+                    // hand over leaf by leaf in node order, as below
+                    int done = -1;
+                    for (;;) {
+                        int next = INT_MAX;
+#pragma unroll
+                        for (int a = 0; a < CSG_FAST; ++a)
+                            if (keep[a] && id[a] > done && id[a] < next) next = id[a];
+                        if (next == INT_MAX) break;
+                        begin_leaf(next);
+#pragma unroll
+                        for (int a = 0; a < CSG_FAST; ++a)
+                            if (keep[a] && id[a] == next) leaf_count<TRACK>(acc, key_time(key[a]));
+                        commit_leaf();
+                        done = next;
+                    }
+                    cl.n = 0;
+                } else {
+                    int kept = first;
+#pragma unroll
+                    for (int a = 0; a < CSG_FAST; ++a)
+                        if (keep[a]) {
+                            cl.t[kept] = key_time(key[a]);
+                            cl.id[kept] = id[a];
+                            ++kept;
+                        }
+                    cl.n = kept;
+                }
+                i = i + 1;
+                if (early && wave_ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
+                continue;
+            }
             for (int a = first + 1; a < last; ++a) {
                 const double ta = cl.t[a];
                 const int ia = cl.id[a];
