@@ -26,69 +26,61 @@ def quantise(img):
 
 
 def test_default_scene_3840x2160(host, orc):
+    """The headline frame, every one of its 8,294,400 pixels against the oracle."""
     W, H = 3840, 2160
     img, st = host.render(scenes.build_world(host), scenes.default_camera(host, W, H), stats=True)
     assert img.shape == (H, W, 3) and np.isfinite(img).all()
     assert st.rays_primary == W * H
-    rng = np.random.default_rng(7)
-    n = 4000
-    xs, ys = rng.integers(0, W, n), rng.integers(0, H, n)
-    # the glass sphere is where the deep recursion happens: oversample its neighbourhood
-    xs[: n // 2] = rng.integers(int(0.35 * W), int(0.65 * W), n // 2)
-    ys[: n // 2] = rng.integers(int(0.25 * H), int(0.75 * H), n // 2)
-    ref = sampled_reference(orc, scenes.build_world(orc), scenes.default_camera(orc, W, H), xs, ys)
-    got = img[ys, xs]
-    assert np.abs(got - ref).max() <= 1e-11
-    assert (quantise(got) != quantise(ref)).sum() == 0
+    ref, cnt = orc.render(scenes.build_world(orc), scenes.default_camera(orc, W, H), threads=16, counters=True)
+    assert np.abs(img - ref).max() <= 1e-11
+    assert np.array_equal(quantise(img), quantise(ref))
+    assert (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract) == \
+        (cnt["rays_primary"], cnt["rays_shadow"], cnt["rays_reflect"], cnt["rays_refract"])
     # bytes = Canvas::clamp of the colours, everywhere
     img8 = host.render_u8(scenes.build_world(host), scenes.default_camera(host, W, H))
     assert np.array_equal(img8, quantise(img).astype(np.uint8))
 
 
 def test_8k_frame_from_eight_ranks(host, orc):
-    """7680x4320 as the multi-GPU runs partition it: each of 8 ranks renders its cyclic 8-row tiles;
-    a sample of pixels from every rank's rows is checked against the oracle, and two ranks' buffers
-    are compared bit for bit with the corresponding rows of a 2-rank partition."""
+    """7680x4320 as the multi-GPU runs partition it: each of 8 ranks renders its cyclic 8-row tiles
+    (here one after the other on one GPU); the rows of all ranks together are the oracle's frame,
+    all 33,177,600 pixels of it, and a 2-rank partition gives the same rows bit for bit."""
     W, H = 7680, 4320
     world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
-    oworld, ocam = scenes.build_world(orc), scenes.default_camera(orc, W, H)
-    rng = np.random.default_rng(11)
-    parts = {}
-    for rank in (0, 3, 7):
+    ref = orc.render(scenes.build_world(orc), scenes.default_camera(orc, W, H), threads=16)
+    seen = np.zeros(H, dtype=bool)
+    part0 = rows0 = None
+    for rank in range(8):
         part = host.render(world, cam, rank=rank, world_size=8)
         rows = host.global_rows(H, rank, 8)
-        assert part.shape == (len(rows), W, 3)
-        parts[rank] = (part, rows)
-        k = rng.integers(0, len(rows), 500)
-        xs = rng.integers(0, W, 500)
-        ref = sampled_reference(orc, oworld, ocam, xs, rows[k])
-        assert np.abs(part[k, xs] - ref).max() <= 1e-11
+        assert part.shape == (len(rows), W, 3) and not seen[rows].any()
+        seen[rows] = True
+        assert np.abs(part - ref[rows]).max() <= 1e-11
+        assert np.array_equal(quantise(part), quantise(ref[rows]))
+        if rank == 0:
+            part0, rows0 = part, rows
+    assert seen.all()
     # rank 0 of 8 owns tiles 0, 8, 16, ...; rank 0 of 2 owns tiles 0, 2, 4, ...: shared rows must agree exactly
     half = host.render(world, cam, rank=0, world_size=2)
     half_rows = host.global_rows(H, 0, 2)
-    part, rows = parts[0]
     pos = {int(r): i for i, r in enumerate(half_rows)}
-    idx = np.array([pos[int(r)] for r in rows])
-    assert np.array_equal(half[idx], part)
+    idx = np.array([pos[int(r)] for r in rows0])
+    assert np.array_equal(half[idx], part0)
 
 
-@pytest.mark.parametrize("name", ["glass", "csg", "smooth_teapot", "dragon"])
+@pytest.mark.parametrize("name", ["glass", "csg", "field", "teapot", "smooth_teapot", "dragon"])
 def test_other_workloads_1920x1080(host, orc, name):
-    """The glass/pattern, CSG and mesh configurations at the size they are benchmarked at: a sample
-    of pixels against the oracle, and bytes = Canvas::clamp of the colours everywhere."""
+    """The glass/pattern, CSG, loose-object and mesh configurations at the size they are benchmarked
+    at: every pixel and the ray counts against the oracle, and bytes = Canvas::clamp of the colours."""
     W, H = 1920, 1080
     mw, mc = scenes.WORKLOADS[name]
     img, st = host.render(mw(host), mc(host, W, H), stats=True)
     assert img.shape == (H, W, 3) and st.rays_primary == W * H
-    rng = np.random.default_rng(13)
-    n = 1500
-    xs, ys = rng.integers(0, W, n), rng.integers(0, H, n)
-    xs[: n // 2] = rng.integers(int(0.3 * W), int(0.7 * W), n // 2)   # where the objects are
-    ys[: n // 2] = rng.integers(int(0.3 * H), int(0.8 * H), n // 2)
-    ref = sampled_reference(orc, mw(orc), mc(orc, W, H), xs, ys)
-    got = img[ys, xs]
-    assert np.abs(got - ref).max() <= 1e-11
-    assert (quantise(got) != quantise(ref)).sum() == 0
+    ref, cnt = orc.render(mw(orc), mc(orc, W, H), threads=16, counters=True)
+    assert np.abs(img - ref).max() <= 1e-11
+    assert np.array_equal(quantise(img), quantise(ref))
+    assert (st.rays_shadow, st.rays_reflect, st.rays_refract) == \
+        (cnt["rays_shadow"], cnt["rays_reflect"], cnt["rays_refract"])
     img8 = host.render_u8(mw(host), mc(host, W, H))
     assert np.array_equal(img8, quantise(img).astype(np.uint8))
 
@@ -119,3 +111,15 @@ def test_two_frames_in_flight(host):
         pipe.wait()
         for slot in range(2):
             assert np.array_equal(buffers[slot].cpu().numpy(), want[order[slot]]), (pair, slot)
+
+
+def test_ragged_frame_with_cost_ordered_tiles(host, orc):
+    """1003x517: neither side a multiple of the 8-pixel tile, and enough tiles (8190) for the cost
+    pre-pass and the reordered dispatch; every pixel against the oracle."""
+    W, H = 1003, 517
+    mw, mc = scenes.WORKLOADS["default"]
+    img = host.render(mw(host), mc(host, W, H))
+    ref = orc.render(mw(orc), mc(orc, W, H), threads=16)
+    assert img.shape == ref.shape == (H, W, 3)
+    assert np.abs(img - ref).max() <= 1e-11
+    assert np.array_equal(quantise(img), quantise(ref))
