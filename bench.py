@@ -51,11 +51,14 @@ def cpu_baseline(name, W, H, budget_s=15.0):
     starts = [int((k + 0.5) * H / n_bands) // band * band for k in range(n_bands)]
     rays = 0
     seconds = 0.0
+    seconds_fast = 0.0
     rows = 0
     for r0 in starts:
         r1 = min(r0 + band, H)
         orc.set_faithful(False)
+        t = time.perf_counter()
         _, cnt = orc.render(world, cam, threads=threads, rows=(r0, r1), counters=True)
+        seconds_fast += time.perf_counter() - t
         orc.set_faithful(True)
         t = time.perf_counter()
         orc.render(world, cam, threads=threads, rows=(r0, r1))
@@ -74,6 +77,9 @@ def cpu_baseline(name, W, H, budget_s=15.0):
         "sample": "%d rows (%d evenly spaced bands of %d) of the %dx%d %s frame, %.1f s; rays counted "
                   "once per hit as on the GPU, timed in the cost-faithful mode" % (rows, len(starts), band, W, H, name, seconds),
         "host_cpus": os.cpu_count(),
+        # the same rows with every inverse computed once per shape instead of once per use (what the
+        # GPU path's host side does too): how much of the reference's CPU cost is that recomputation
+        "value_with_cached_inverses": rays / seconds_fast / 1e6 if seconds_fast > 0 else None,
     }
 
 
