@@ -1026,14 +1026,14 @@ DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
     return acc;
 }
 
-// Wavefronts per SIMD the register allocation aims for.  Four (128 VGPRs) is the most that fits
-// every variant without spilling; at five (96 VGPRs) a few spills land in the traversal loops
-// whenever the code around them changes, which costs more than the fifth wavefront hides.
+// Wavefronts per SIMD the register allocation aims for.  Five (96 VGPRs) fit once the shading state
+// waits in LDS during the shadow walks (three spilled registers, saved before the bounce loop and
+// restored after it); the variants for scenes with CSG shapes would spill forty and stay at four.
 #ifndef RT_MIN_WAVES
-#define RT_MIN_WAVES 4
+#define RT_MIN_WAVES 5
 #endif
-#ifndef RT_MIN_WAVES_XF
-#define RT_MIN_WAVES_XF 4
+#ifndef RT_MIN_WAVES_CSG
+#define RT_MIN_WAVES_CSG 4
 #endif
 #ifndef RT_BLOCK_WAVES
 #define RT_BLOCK_WAVES 1  // wavefronts (8x8 tiles) per workgroup; one gives the dispatcher the finest grain
@@ -1158,7 +1158,7 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, i
 }
 
 template <bool TRACK, bool XF, bool CULL, bool CSGM>
-__global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
+__global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters,
                                                  unsigned long long* __restrict__ clear_counters) {
     const int lane = threadIdx.x & 63;
@@ -1173,6 +1173,11 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
     // wavefront's rounds; the tile is written from there at the end.
     __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
     double* const my_pixel = tile_lds[wave] + lane * 3;
+    // What is only needed again after a shadow walk waits in LDS meanwhile ([value][lane]: no bank
+    // conflicts), which keeps it out of the registers the walk needs: 127 -> 113 VGPRs at four
+    // wavefronts per SIMD, and five fit.  6 KB per wavefront; 20 wavefronts fill a CU's 160 KB.
+    __shared__ double park_lds[RT_BLOCK_WAVES][12][64];
+    double (*const park)[64] = park_lds[wave];
     my_pixel[0] = 0.0;
     my_pixel[1] = 0.0;
     my_pixel[2] = 0.0;
@@ -1413,7 +1418,25 @@ __global__ void __launch_bounds__(RT_BLOCK, XF ? RT_MIN_WAVES_XF : RT_MIN_WAVES)
 #ifdef RT_PROFILE
             unsigned long long ps = __builtin_amdgcn_s_memtime();
 #endif
+            park[0][lane] = normalv.x;
+            park[1][lane] = normalv.y;
+            park[2][lane] = normalv.z;
+            park[3][lane] = colour.x;
+            park[4][lane] = colour.y;
+            park[5][lane] = colour.z;
+            park[6][lane] = rd.x;
+            park[7][lane] = rd.y;
+            park[8][lane] = rd.z;
+            park[9][lane] = acc.x;
+            park[10][lane] = acc.y;
+            park[11][lane] = acc.z;
+            asm volatile("" ::: "memory");  // the values must really leave the registers ...
             trace<MODE_SHADOW, XF, CULL, CSGM>(S, shadow_matters, over, lightv, distance, sh);
+            asm volatile("" ::: "memory");  // ... and come back from LDS, not from a copy the compiler kept
+            normalv = mk(park[0][lane], park[1][lane], park[2][lane]);
+            colour = mk(park[3][lane], park[4][lane], park[5][lane]);
+            rd = mk(park[6][lane], park[7][lane], park[8][lane]);
+            acc = mk(park[9][lane], park[10][lane], park[11][lane]);
 #ifdef RT_PROFILE
             prof_shadow += __builtin_amdgcn_s_memtime() - ps;
             prof_visits += sh.visits;
