@@ -19,7 +19,7 @@ LIB = os.path.join(HERE, "liboracle.so")
 COUNTER_NAMES = [
     "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "aabb_test", "sphere_test",
     "plane_test", "cube_test", "cyl_test", "cone_test", "tri_test", "ray_xform", "shaded_hits",
-    "light_evals", "pattern_nodes", "inverses", "flops", "xform_nonident",
+    "light_evals", "pattern_nodes", "inverses", "flops", "xform_nonident", "smooth_hits",
 ]
 
 

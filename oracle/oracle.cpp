@@ -51,6 +51,7 @@ struct Counters {
     // abs/compare/pow/cos on 3-component vectors and 3x4 affine matrices), accumulated with the
     // per-event constants written next to each `g_cnt.flops +=`; and the non-identity ray transforms.
     uint64_t flops = 0, xform_nonident = 0;
+    uint64_t smooth_hits = 0;  // shaded hits on smooth triangles (their three vertex normals are read)
     void add(const Counters& o) {
         const uint64_t* s = reinterpret_cast<const uint64_t*>(&o);
         uint64_t* d = reinterpret_cast<uint64_t*>(this);
@@ -1015,6 +1016,7 @@ struct World {
     static Comps prepare(int hit_idx, const Ray& ray, const std::vector<Hit>& xs) {
         ++g_cnt.shaded_hits;
         const Hit& h = xs[hit_idx];
+        if (h.obj->kind == S_SMOOTH) ++g_cnt.smooth_hits;
         {
             static const int normal_cost[8] = {0, 3, 15, 8, 8, 8, 0, 17};
             uint64_t f = 60 + normal_cost[h.obj->kind];
@@ -1821,7 +1823,7 @@ int orc_is_shadowed(int64_t w, const double* p, const double* lpos, const double
 
 // render (lib.rs:77-133): rows [row0, row1) of the camera.width() x camera.height() canvas into
 // rgb (full-frame layout, (y*W + x)*3).  Work is split over `threads` workers striding the linear
-// pixel index like lib.rs:94-111.  counters (16 x u64) may be NULL.
+// pixel index like lib.rs:94-111.  counters (orc_num_counters() x u64) may be NULL.
 static void warm_bounds(Shape* s) {
     if (s->kind != S_GROUP && s->kind != S_CSG) return;
     s->bounds();
