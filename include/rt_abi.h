@@ -37,6 +37,8 @@ typedef enum rt_status {
 #define RT_MAX_PATTERN_NEST 4  /* nested gradient/blended patterns */
 #define RT_TILE 8              /* a wavefront renders an 8x8 pixel tile */
 #define RT_MAX_CSG_NEST 4      /* CSG shapes nested inside one another */
+#define RT_STATIC_MAX_TILES (1 << 19) /* most 8x8 tiles of one rt_render_device_static call: a 7680x4320
+                                         frame has 518,400 */
 #define RT_MAX_CSG_HITS 24     /* most intersections one ray can have with an outermost CSG shape:
                                   sphere, cube 2 each; cylinder, cone 4; plane, triangles 1 */
 
@@ -156,7 +158,18 @@ int64_t rt_global_row(int64_t local_row, const rt_params* params);
  * is asynchronous on `hip_stream` (a hipStream_t, may be NULL for the default stream). */
 int rt_render_device(rt_scene* scene, const rt_camera* camera, const rt_params* params,
                      double* d_rgb, void* hip_stream);
-/* Same, but synchronous into HOST memory; fills stats when not NULL. */
+/* No counterpart in the reference.  rt_render_device for callers that cannot allocate device
+ * memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc): the
+ * scratch a launch needs beyond the frame -- one set of ray counters and the tile dispatch order,
+ * 8.1 MB -- is a fixed array inside the library instead of buffers a scene allocates on demand, so
+ * the call allocates and frees nothing.  It renders the same pixels as rt_render_device.  The part
+ * of the frame `params->rank` renders may have at most RT_STATIC_MAX_TILES 8x8 tiles (RT_ERR_LIMIT
+ * beyond that).  Every call on a GPU uses that GPU's one array: calls that overlap on one GPU (two
+ * streams, two scenes, two threads) race; calls on different GPUs do not.  rt_scene_ray_counts
+ * after it reports this call's rays until the next launch on the GPU. */
+int rt_render_device_static(rt_scene* scene, const rt_camera* camera, const rt_params* params,
+                            double* d_rgb, void* hip_stream);
+/* Same as rt_render_device, but synchronous into HOST memory; fills stats when not NULL. */
 int rt_render(rt_scene* scene, const rt_camera* camera, const rt_params* params, double* rgb_out,
               rt_stats* stats);
 /* render followed by Canvas::clamp on every channel (src/canvas.rs:50-60: 255*c saturated to

@@ -10,6 +10,7 @@ RT_MAX_DEPTH = 5
 RT_MAX_XFORM_NEST = 4
 RT_MAX_PATTERN_NEST = 4
 RT_TILE = 8
+RT_STATIC_MAX_TILES = 1 << 19
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_LIMIT, RT_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 RT_NODE_CASTS_SHADOW, RT_NODE_CLOSED = 1, 2
 
@@ -94,6 +95,8 @@ SYMBOLS = {
     "rt_global_row": (C.c_int64, [C.c_int64, C.POINTER(rt_params)]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p,
                                    C.c_void_p]),
+    "rt_render_device_static": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p,
+                                          C.c_void_p]),
     "rt_render": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.POINTER(c_d),
                             C.POINTER(rt_stats)]),
     "rt_render_device_u8": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p,

@@ -30,6 +30,7 @@
 #include <cstring>
 #include <cstdint>
 #include <cstdlib>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -1712,6 +1713,33 @@ int fail(int code, const std::string& msg) {
 
 constexpr int TIMING_RING = 256;
 
+// Scratch of rt_render_device_static: one set of ray counters followed by the tile dispatch order
+// (three order arrays and the tile classes).  Every GPU the library runs on holds its own copy at its
+// own address until the process ends; host code never uses the array's name as an address, only
+// the per-device pointer hipGetSymbolAddress returned (static_scratch_for).
+constexpr size_t STATIC_COUNTER_BYTES = ((COUNTER_SET_WORDS * sizeof(unsigned long long)) + 255) & ~(size_t)255;
+constexpr size_t STATIC_ORDER_BYTES = 4 * (size_t)RT_STATIC_MAX_TILES * sizeof(int);
+constexpr size_t STATIC_SCRATCH_BYTES = STATIC_COUNTER_BYTES + STATIC_ORDER_BYTES;
+static __device__ __align__(256) unsigned char scratch[STATIC_SCRATCH_BYTES];
+
+constexpr int MAX_DEVICES = 64;
+std::mutex g_scratch_mutex;
+unsigned char* g_scratch_ptr[MAX_DEVICES] = {};
+
+// Address of `scratch` on `device`, which must be the current device.  Looked up once per device.
+int static_scratch_for(int device, unsigned char** out) {
+    if (device < 0 || device >= MAX_DEVICES) return fail(RT_ERR_INVALID, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(RT_ERR_HIP, "hipGetSymbolAddress returned a null address");
+        g_scratch_ptr[device] = (unsigned char*)p;
+    }
+    *out = g_scratch_ptr[device];
+    return RT_OK;
+}
+
 }  // namespace
 
 struct rt_scene {
@@ -1730,7 +1758,9 @@ struct rt_scene {
     int* d_order = nullptr;                     // tiles of the current frame by cost class (3 arrays)
     long long order_cap = 0;
     bool set_clean[2] = {true, true};
-    int next_set = 0, last_set = 0;
+    int next_set = 0;
+    unsigned long long* last_counters = nullptr;  // the counter set the most recent launch wrote
+    unsigned char* static_scratch = nullptr;       // this device's copy of `scratch` (rt_render_device_static)
     double* d_frame = nullptr;  // staging for the synchronous entry points
     size_t frame_bytes = 0;
     double* d_rays = nullptr;
@@ -2377,26 +2407,39 @@ int local_tile_rows(int height, const rt_params* p) {
 // Frames with at least this many tiles are rendered expensive tiles first (see tile_class_kernel).
 constexpr long long ORDER_MIN_TILES = 4096;
 
-int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t stream) {
+// fixed: null, or this device's static scratch (rt_render_device_static): the launch then uses the
+// counter set and the order arrays in it and allocates nothing.
+int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t stream, unsigned char* fixed = nullptr) {
     int slot = (int)(s->launches % TIMING_RING);
     // Launches on one scene must be ordered (one stream at a time): each clears the other counter set.
     const int a = s->next_set, b = a ^ 1;
     unsigned long long* mine = s->d_counters + (size_t)a * COUNTER_SET_WORDS;
     unsigned long long* other = s->d_counters + (size_t)b * COUNTER_SET_WORDS;
-    if (!s->set_clean[a]) HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), stream));
-    const bool clears_other = blocks >= (COUNTER_SET_WORDS + RT_BLOCK - 1) / RT_BLOCK;  // enough threads to reach every word
+    int* order = s->d_order;
     const long long tiles = job.n_rays > 0 ? 0 : (long long)job.tiles_x * job.local_tile_rows;
+    if (fixed) {
+        // The array keeps the last call's contents: the counters (ray counts, tiles per class) must
+        // start at zero; the order arrays are rewritten by the pre-pass before they are read.
+        mine = reinterpret_cast<unsigned long long*>(fixed);
+        other = nullptr;
+        order = reinterpret_cast<int*>(fixed + STATIC_COUNTER_BYTES);
+        HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), stream));
+    } else if (!s->set_clean[a]) {
+        HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), stream));
+    }
+    const bool clears_other = other && blocks >= (COUNTER_SET_WORDS + RT_BLOCK - 1) / RT_BLOCK;  // enough threads to reach every word
     static const bool order_enabled = !(getenv("RT_TILE_ORDER") && atoi(getenv("RT_TILE_ORDER")) == 0);
     job.tile_order = nullptr;
     if (order_enabled && s->order_useful && tiles >= ORDER_MIN_TILES) {
-        if (tiles > s->order_cap) {
+        if (!fixed && tiles > s->order_cap) {
             if (s->d_order) HIP_TRY(hipFree(s->d_order));
             s->d_order = nullptr;
             s->order_cap = 0;
             HIP_TRY(hipMalloc((void**)&s->d_order, 4 * (size_t)tiles * sizeof(int)));  // three order arrays and the classes
             s->order_cap = tiles;
+            order = s->d_order;
         }
-        job.tile_order = s->d_order;
+        job.tile_order = order;
         job.tile_class_count = mine + COUNTER_WORDS;
     }
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
@@ -2407,11 +2450,11 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
         static const Pre pres[4] = {tile_class_kernel<false, false, false>, tile_class_kernel<false, true, false>,
                                     tile_class_kernel<true, false, false>, tile_class_kernel<true, true, false>};
         Pre prek = s->any_csg ? tile_class_kernel<true, true, true> : pres[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
-        int* classes = s->d_order + 3 * tiles;
+        int* classes = order + 3 * tiles;
         hipLaunchKernelGGL(prek, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, s->dev, pre, tiles, classes);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)((tiles + ORDER_BLOCK - 1) / ORDER_BLOCK)), dim3(ORDER_BLOCK), 0, stream, job.tiles_x,
-                           job.local_tile_rows, tiles, (const int*)classes, s->d_order, mine + COUNTER_WORDS);
+                           job.local_tile_rows, tiles, (const int*)classes, order, mine + COUNTER_WORDS);
         HIP_TRY(hipGetLastError());
     }
     if (blocks > 0) {
@@ -2429,10 +2472,12 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
         HIP_TRY(hipGetLastError());
     }
     HIP_TRY(hipEventRecord(s->ev_stop[slot], stream));
-    s->set_clean[a] = blocks == 0;
-    if (clears_other) s->set_clean[b] = true;
-    s->last_set = a;
-    s->next_set = b;
+    if (!fixed) {
+        s->set_clean[a] = blocks == 0;
+        if (clears_other) s->set_clean[b] = true;
+        s->next_set = b;
+    }
+    s->last_counters = mine;
     s->launches++;
     s->last_stream = stream;
     return RT_OK;
@@ -2441,7 +2486,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
 int fill_stats(rt_scene* s, rt_stats* st) {
     if (!st) return RT_OK;
     std::vector<unsigned long long> shards(COUNTER_SHARDS * 16);
-    HIP_TRY(hipMemcpy(shards.data(), s->d_counters + (size_t)s->last_set * COUNTER_SET_WORDS,
+    HIP_TRY(hipMemcpy(shards.data(), s->last_counters ? s->last_counters : s->d_counters,
                       shards.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     unsigned long long c[16] = {};
     for (unsigned k = 0; k < COUNTER_SHARDS; ++k)
@@ -2490,8 +2535,11 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
     if (device < 0 || device >= ndev) return fail(RT_ERR_INVALID, "device ordinal out of range");
     HIP_TRY(hipSetDevice(device));
+    unsigned char* static_scratch = nullptr;
+    if ((rc = static_scratch_for(device, &static_scratch)) != RT_OK) return rc;
     rt_scene* s = new rt_scene();
     s->device = device;
+    s->static_scratch = static_scratch;
     s->any_transparent = any_transparent;
     auto cleanup = [&](int code) {
         rt_scene_destroy(s);
@@ -2584,7 +2632,7 @@ int64_t rt_global_row(int64_t local_row, const rt_params* p) {
 }
 
 static int render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, void* d_rgb, bool out_u8,
-                         void* hip_stream) {
+                         void* hip_stream, bool use_static = false) {
     if (!s || !cam) return fail(RT_ERR_INVALID, "null scene or camera");
     int rc = check_params(prm);
     if (rc != RT_OK) return rc;
@@ -2612,7 +2660,14 @@ static int render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm
     if (tiles > 0 && !d_rgb) return fail(RT_ERR_INVALID, "null output buffer");
     long long blocks = (tiles + RT_BLOCK_WAVES - 1) / RT_BLOCK_WAVES;
     if (blocks > 0x7fffffffLL) return fail(RT_ERR_LIMIT, "frame too large for one launch");
-    return launch(s, job, (unsigned)blocks, (double*)d_rgb, (hipStream_t)hip_stream);
+    if (use_static) {
+        if (tiles > RT_STATIC_MAX_TILES)
+            return fail(RT_ERR_LIMIT, "rt_render_device_static: this rank's part of the frame has more than "
+                                      "RT_STATIC_MAX_TILES 8x8 tiles");
+        if (!s->static_scratch) return fail(RT_ERR_HIP, "the static scratch array has no address on this device");
+    }
+    return launch(s, job, (unsigned)blocks, (double*)d_rgb, (hipStream_t)hip_stream,
+                  use_static ? s->static_scratch : nullptr);
 }
 
 int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* d_rgb, void* hip_stream) {
@@ -2621,6 +2676,10 @@ int rt_render_device(rt_scene* s, const rt_camera* cam, const rt_params* prm, do
 
 int rt_render_device_u8(rt_scene* s, const rt_camera* cam, const rt_params* prm, uint8_t* d_rgb8, void* hip_stream) {
     return render_device(s, cam, prm, d_rgb8, true, hip_stream);
+}
+
+int rt_render_device_static(rt_scene* s, const rt_camera* cam, const rt_params* prm, double* d_rgb, void* hip_stream) {
+    return render_device(s, cam, prm, d_rgb, false, hip_stream, true);
 }
 
 static int render_host(rt_scene* s, const rt_camera* cam, const rt_params* prm, void* out, bool out_u8,

@@ -1,0 +1,65 @@
+"""rt_render_device_static: the render entry point that allocates nothing (its ray counters and
+tile dispatch order live in a fixed array inside the library) must give exactly what
+rt_render_device gives, call after call, also when a smaller frame follows a larger one in the same
+array."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, scenes
+
+pytestmark = pytest.mark.gpu
+
+
+def _render(host, fn, scene, cam, buf, torch):
+    prm = abi.rt_params(5, 0, 1, 0)
+    buf.fill_(float("nan"))
+    rc = fn(scene, C.byref(cam), C.byref(prm), C.c_void_p(buf.data_ptr()), C.c_void_p(0))
+    assert rc == 0, host.abi.rt_last_error()
+    torch.cuda.synchronize()
+    st = abi.rt_stats()
+    assert host.abi.rt_scene_ray_counts(scene, C.byref(st)) == 0
+    return buf.cpu().numpy().copy(), (st.rays_primary, st.rays_shadow, st.rays_reflect, st.rays_refract)
+
+
+@pytest.mark.parametrize("name", ["default", "teapot"])
+def test_static_scratch_render_equals_render_device(host, name):
+    torch = pytest.importorskip("torch")
+    lib = host.abi
+    mw, mc = scenes.WORKLOADS[name]
+    world = mw(host)
+    scene = host.scene_handle(world, device=0)
+    dev = torch.device("cuda", 0)
+    # two calls in a row on the same array; the second frame is smaller and ragged (and still has
+    # enough tiles, 8190, for the cost-ordered dispatch that uses the order arrays)
+    for W, H in ((1920, 1080), (1003, 517)):
+        cam = host.camera_block(mc(host, W, H))
+        buf = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
+        want, want_rays = _render(host, lib.rt_render_device, scene, cam, buf, torch)
+        got, got_rays = _render(host, lib.rt_render_device_static, scene, cam, buf, torch)
+        assert np.isfinite(want).all()
+        assert np.array_equal(got, want), (name, W, H)
+        assert got_rays == want_rays and got_rays[0] == W * H
+    # the plain entry point still works after the static one, and agrees with itself
+    again, _ = _render(host, lib.rt_render_device, scene, cam, buf, torch)
+    assert np.array_equal(again, want)
+
+
+def test_static_scratch_render_rejects_frames_beyond_its_array(host):
+    torch = pytest.importorskip("torch")
+    lib = host.abi
+    world = scenes.build_world(host)
+    scene = host.scene_handle(world, device=0)
+    cam = host.camera_block(scenes.default_camera(host, 8192, 8192))  # 1,048,576 tiles
+    assert (8192 // 8) ** 2 > abi.RT_STATIC_MAX_TILES
+    buf = torch.zeros(16, dtype=torch.float64, device="cuda:0")  # never written: the call is refused first
+    prm = abi.rt_params(5, 0, 1, 0)
+    rc = lib.rt_render_device_static(scene, C.byref(cam), C.byref(prm), C.c_void_p(buf.data_ptr()), C.c_void_p(0))
+    assert rc == abi.RT_ERR_LIMIT and b"RT_STATIC_MAX_TILES" in lib.rt_last_error()
+    torch.cuda.synchronize()
+    assert not buf.cpu().numpy().any()
+    # split over two ranks the same frame fits: the limit is on what one call renders
+    prm2 = abi.rt_params(5, 1, 2, 0)
+    rows = lib.rt_local_rows(8192, C.byref(prm2))
+    assert rows * (8192 // 8) // 8 <= abi.RT_STATIC_MAX_TILES
