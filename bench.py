@@ -1,20 +1,28 @@
 """Benchmark of the render path: Mrays/s (primary + secondary) and frame time.
 
-  python bench.py --gpus 1 --steps K --warmup W            single GPU, default scene at 3840x2160
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
-                                                          N GPUs, default scene at 7680x4320, the
-                                                          frame split into cyclic 8-row tiles and
-                                                          gathered to rank 0 over RCCL
+  python bench.py [--gpus N] [--steps K] [--warmup W]
 
-A step renders one frame from tables already resident in HBM into HBM (at N > 1 it also gathers the
-ranks' tiles into rank 0's full frame).  Rank 0 prints ONE JSON line.
+One experiment at every N: the reference's default scene (src/lib.rs:135-323) at 7680x4320, depth 5,
+split into cyclic 8-row tiles over N ranks (one process per GPU), every rank storing the clamped
+bytes the PPM prints; at N > 1 rank 0 collects the ranks' tiles over RCCL while the next frame
+renders.  With N > 1 and no torch.distributed launcher around it, the script starts its own N worker
+processes (fresh interpreters, started before anything touches a GPU).  Rank 0 prints ONE JSON line.
 
-`roofline` prices the render kernel against the FP64 vector peak: achieved = algorithmic f64
-operations of the frame (counted by the CPU oracle with fixed per-event costs, profiles/work_*.json)
-/ the kernel's mean device time from HIP events on its launch stream.
-`cpu_baseline` times the CPU restatement of the reference in its cost-faithful mode (inverse
-recomputed per use, secondary rays re-traced per light, 12 worker threads like src/lib.rs:23) on a
-bounded sample of rows of the same frame, on this machine's host cores.
+A step renders one frame from tables already resident in HBM into HBM.  Besides the timed region
+the line carries:
+  frame_latency_ms, kernel_ms, gather_ms, d2h_ms   one frame at a time, nothing overlapped
+  roofline      the render kernel against the FP64 vector peak: algorithmic f64 operations of the
+                frame (counted by the CPU oracle, profiles/work_*.json) / the kernel's mean launch
+                duration (HIP events on its stream); HBM traffic and executed operations from the
+                rocprofv3 PMC passes committed under profiles/ (profiles/pmc.json)
+and at N = 1 only:
+  single_gpu_4k the same scene at 3840x2160 with the f64 frame store (the single-GPU configuration)
+  e2e           wall time per frame of the host-memory entry points rt_render / rt_render_u8 /
+                rt_render_ppm, and the measured page-locked PCIe rate
+  scene_build   host-side time to parse, divide, flatten, lay out and upload two large scenes
+  cpu_baseline  the CPU restatement of the reference in its cost-faithful mode (inverse recomputed
+                per use, secondary rays re-traced per light, 12 worker threads like src/lib.rs:23) on
+                a bounded sample of rows of the same frame, on this machine's host cores.
 """
 import argparse
 import ctypes
@@ -30,12 +38,22 @@ FP64_VECTOR_PEAK_TFLOPS = 78.6  # 256 CU x 128 FLOP/clk x 2.4 GHz, FMA counted a
 HBM_PEAK_GBS = 8000.0
 
 
-def load_work(name, W, H):
-    path = os.path.join(ROOT, "profiles", "work_%s_%dx%d.json" % (name, W, H))
+def load_json(*parts):
+    path = os.path.join(ROOT, *parts)
     if os.path.exists(path):
         with open(path) as f:
             return json.load(f)
     return None
+
+
+def load_work(name, W, H):
+    return load_json("profiles", "work_%s_%dx%d.json" % (name, W, H))
+
+
+def load_pmc(workload, W, H):
+    """What rocprofv3's PMC passes measured per launch on this configuration (profiles/pmc.json)."""
+    table = load_json("profiles", "pmc.json") or {}
+    return table.get("%s_%dx%d" % (workload, W, H))
 
 
 def cpu_baseline(name, W, H, budget_s=15.0):
@@ -74,55 +92,267 @@ def cpu_baseline(name, W, H, budget_s=15.0):
         "unit": "Mrays/s",
         "cores": threads,
         "kind": "port",
-        "sample": "%d rows (%d evenly spaced bands of %d) of the %dx%d %s frame, %.1f s; rays counted "
-                  "once per hit as on the GPU, timed in the cost-faithful mode" % (rows, len(starts), band, W, H, name, seconds),
+        "sample": "%d rows (evenly spaced bands of %d) of the %dx%d %s frame, %.1f s; rays counted "
+                  "once per hit as on the GPU, timed in the cost-faithful mode" % (rows, band, W, H, name, seconds),
         "host_cpus": os.cpu_count(),
+        "cargo_on_path": bool(__import__("shutil").which("cargo")),  # the Rust reference itself needs it (and its crates)
         # the same rows with every inverse computed once per shape instead of once per use (what the
         # GPU path's host side does too): how much of the reference's CPU cost is that recomputation
         "value_with_cached_inverses": rays / seconds_fast / 1e6 if seconds_fast > 0 else None,
     }
 
 
-def load_traffic(workload, W, H):
-    """HBM bytes per launch measured with rocprofv3 PMC passes on this workload (profiles/traffic.json), or None."""
-    path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
-    entry = json.load(open(path)).get("%s_%dx%d" % (workload, W, H))
-    return entry["bytes_per_launch"] if entry else None
+def roofline_block(work, pmc, flops_share, kernel_ms, frame_bytes, W, H):
+    """flops_share: this launch's part of the frame's algorithmic operations."""
+    achieved = flops_share / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+    r = {
+        "bound": "valu-fp64",
+        "achieved": achieved,
+        "peak": FP64_VECTOR_PEAK_TFLOPS,
+        "unit": "TFLOP/s",
+        "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
+        "frac_is": "operations of the REFERENCE's algorithm for this frame (oracle count) per second / peak; the kernel "
+                   "skips work whose outcome is known (cull boxes, pruned subtrees), so on meshes this exceeds what the "
+                   "ALUs execute: see frac_executed",
+        "traffic": pmc["bytes_per_launch"] if pmc else None,
+        "peak_without_fma": FP64_VECTOR_PEAK_TFLOPS / 2,
+        "frac_without_fma": achieved / (FP64_VECTOR_PEAK_TFLOPS / 2),
+        "algorithmic_flops_per_launch": flops_share,
+        "kernel_ms": kernel_ms,
+    }
+    if pmc and pmc.get("executed_flops"):
+        ex = pmc["executed_flops"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        r["executed_flops"] = pmc["executed_flops"]  # 64 lanes x (f64 add + mul + 2 fma + transcendental) wave instructions
+        r["executed_tflops"] = ex
+        r["frac_executed"] = ex / FP64_VECTOR_PEAK_TFLOPS
+        r["valu_insts"] = pmc.get("valu_insts")
+        r["pmc_source"] = pmc.get("source")
+    # the secondary roof.  Algorithmic bytes: every group box tested (48 B + 8 B of links), every
+    # triangle tested (p1, e1, e2 = 72 B), the three vertex normals of every smooth triangle shaded
+    # (72 B) and the frame itself.
+    if work is not None:
+        scene_bytes = 56 * work.get("aabb_test", 0) + 72 * work.get("tri_test", 0) + 72 * work.get("smooth_hits", 0)
+        share = flops_share / float(work["flops"]) if work.get("flops") else 1.0
+        alg = scene_bytes * share + frame_bytes
+        r["hbm"] = {
+            "peak_gbs": HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": alg,
+            "algorithmic_bytes_is": "56 x box tests + 72 x triangle tests + 72 x smooth-triangle hits of the reference's "
+                                    "algorithm + the frame store",
+            "frame_bytes": frame_bytes,
+            "algorithmic_gbs": alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
+            "measured_gbs": pmc["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 if pmc and kernel_ms > 0 else None,
+            "measured_frac_of_peak": pmc["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pmc and kernel_ms > 0 else None,
+        }
+    return r
+
+
+def launch_times(host, scene, n):
+    cap = max(1, min(n, 256))
+    ms = (ctypes.c_float * cap)()
+    got = host.abi.rt_scene_launch_times(scene, ms, cap)
+    return [ms[i] for i in range(got)]
+
+
+def timed_renders(host, world, cam, steps, warmup, torch, dev, u8, local_rank, max_depth=5):
+    """Frames one at a time on the current stream: (wall ms per frame, mean launch ms, rays per frame)."""
+    from raytracer_amd import abi
+    W, H = cam.width(), cam.height()
+    buf = torch.empty((H, W, 3), dtype=torch.uint8 if u8 else torch.float64, device=dev)
+    scene = host.scene_handle(world, device=local_rank)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def go():
+        host.render_device(world, cam, buf.data_ptr(), stream=stream, device=local_rank, max_depth=max_depth, u8=u8)
+    for _ in range(warmup):
+        go()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        go()
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / steps * 1e3
+    ms = launch_times(host, scene, steps)
+    st = abi.rt_stats()
+    host.abi.rt_scene_ray_counts(scene, ctypes.byref(st))
+    return wall, sum(ms) / max(len(ms), 1), st.total_rays(), buf
+
+
+def single_gpu_4k(host, torch, dev, local_rank):
+    """The single-GPU configuration: default scene, 3840x2160, f64 frame store, one frame at a time."""
+    from raytracer_amd import scenes
+    W, H = 3840, 2160
+    world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
+    wall, kernel_ms, rays, _ = timed_renders(host, world, cam, 100, 20, torch, dev, False, local_rank)
+    work = load_work("default", W, H)
+    out = {"workload": "default scene, 3840x2160, depth 5, f64 store, 1 frame in flight", "steps": 100,
+           "ms_per_step": wall, "kernel_ms": kernel_ms, "rays_per_frame": rays, "value": rays / wall / 1e3, "unit": "Mrays/s"}
+    if work:
+        out["roofline"] = roofline_block(work, load_pmc("default", W, H), float(work["flops"]), kernel_ms, W * H * 24, W, H)
+    return out
+
+
+def e2e_block(host, torch, dev, local_rank, calls=12):
+    """Wall time per frame of the entry points that hand the frame to HOST memory, at 3840x2160."""
+    import numpy as np
+    from raytracer_amd import abi, scenes
+    W, H = 3840, 2160
+    world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
+    scene = host.scene_handle(world, device=local_rank)
+    block = host.camera_block(cam)
+    prm = abi.rt_params(5, 0, 1, 0)
+    P = ctypes.POINTER
+
+    def mean_ms(fn):
+        fn()
+        fn()  # the first calls allocate staging and fault the destination's pages in
+        t0 = time.perf_counter()
+        for _ in range(calls):
+            fn()
+        return (time.perf_counter() - t0) / calls * 1e3
+
+    out = {"workload": "default scene, 3840x2160, depth 5", "calls": calls}
+    pageable = np.empty((H, W, 3), dtype=np.float64)
+    pinned = host.pinned_empty((H, W, 3), np.float64)
+    pageable8 = np.empty((H, W, 3), dtype=np.uint8)
+    pinned8 = host.pinned_empty((H, W, 3), np.uint8)
+    for key, arr, fn, typ in (("rt_render_ms", pageable, host.abi.rt_render, ctypes.c_double),
+                              ("rt_render_pinned_ms", pinned.array, host.abi.rt_render, ctypes.c_double),
+                              ("rt_render_u8_ms", pageable8, host.abi.rt_render_u8, ctypes.c_uint8),
+                              ("rt_render_u8_pinned_ms", pinned8.array, host.abi.rt_render_u8, ctypes.c_uint8)):
+        ptr = arr.ctypes.data_as(P(typ))
+
+        def call(fn=fn, ptr=ptr):
+            rc = fn(scene, ctypes.byref(block), ctypes.byref(prm), ptr, None)
+            assert rc == 0, host.abi.rt_last_error()
+        out[key] = mean_ms(call)
+    cap = 32 + H * (W * 12 + 1)
+    text = ctypes.create_string_buffer(cap)
+    n = ctypes.c_uint64()
+
+    def ppm():
+        rc = host.abi.rt_render_ppm(scene, ctypes.byref(block), ctypes.byref(prm), text, cap, ctypes.byref(n), None)
+        assert rc == 0, host.abi.rt_last_error()
+    out["rt_render_ppm_ms"] = mean_ms(ppm)
+    out["ppm_bytes"] = int(n.value)
+    # the PCIe rate a page-locked destination gets: the same 199 MB with the copy engine alone
+    frame = torch.empty((H, W, 3), dtype=torch.float64, device=dev)
+    host_pin = torch.empty((H, W, 3), dtype=torch.float64, pin_memory=True)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    host_pin.copy_(frame, non_blocking=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        host_pin.copy_(frame, non_blocking=True)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_ms = e0.elapsed_time(e1) / 5
+    out["frame_bytes"] = W * H * 24
+    out["pinned_copy_ms"] = copy_ms
+    out["pinned_pcie_gbs"] = W * H * 24 / (copy_ms * 1e-3) / 1e9
+    _, kernel_ms, _, _ = timed_renders(host, world, cam, 20, 5, torch, dev, False, local_rank)
+    out["kernel_ms"] = kernel_ms
+    out["kernel_plus_pinned_copy_ms"] = kernel_ms + copy_ms
+    out["rt_render_over_kernel_plus_copy"] = out["rt_render_ms"] / (kernel_ms + copy_ms)
+    out["rt_render_pinned_over_kernel_plus_copy"] = out["rt_render_pinned_ms"] / (kernel_ms + copy_ms)
+    pinned.close()
+    pinned8.close()
+    return out
+
+
+def scene_build_block(host, local_rank):
+    """Host-side cost of getting a large scene onto the GPU: OBJ parse, Group::divide, flatten, the
+    library's record layout, upload."""
+    import math
+    from raytracer_amd import abi, scenes
+    out = {}
+
+    def finish(world, entry):
+        t = time.perf_counter()
+        counts = host.flatten(world)
+        entry["flatten_ms"] = (time.perf_counter() - t) * 1e3
+        t = time.perf_counter()
+        scene = host.scene_handle(world, device=local_rank)
+        entry["scene_create_ms"] = (time.perf_counter() - t) * 1e3
+        info = abi.rt_build_info()
+        host.abi.rt_scene_build_info(scene, ctypes.byref(info))
+        entry.update({"validate_ms": info.validate_ms, "records_ms": info.records_ms, "upload_ms": info.upload_ms,
+                      "nodes": counts["nodes"], "triangles": counts["tris"], "records": info.n_records,
+                      "cull_records": info.n_cull_records})
+        return entry
+
+    M, Phong, Solid, Color = host.Matrix, host.Phong, host.Solid, host.Color
+    mat = Phong(Solid(Color(0.8, 0.33, 0.2)), 0.1, 0.7, 0.3, 200.0, 0.0, 0.0, 1.0)
+    t = time.perf_counter()
+    parser = host.ObjFileParser.parse_obj_file(os.path.join(scenes.OBJ_DIR, "dragon.obj"), M.identity(), mat, True)
+    group = parser.obj_to_group(M.identity())
+    parse_ms = (time.perf_counter() - t) * 1e3
+    t = time.perf_counter()
+    group.divide(1)
+    divide_ms = (time.perf_counter() - t) * 1e3
+    floor = host.Plane(M.translation(0.0, -0.2, 0.0), Phong.default(), True)
+    world = host.World([floor, group], [host.PointLight(host.point(-10.0, 10.0, -10.0), Color.white())])
+    out["dragon"] = finish(world, {"parse_ms": parse_ms, "divide_ms": divide_ms})
+    t = time.perf_counter()
+    world = scenes.loose_triangles_world(host)
+    out["loose_triangles_20300"] = finish(world, {"construct_ms": (time.perf_counter() - t) * 1e3, "divide_ms": 0.0})
+    for e in out.values():
+        e["total_ms"] = sum(v for k, v in e.items() if k in ("parse_ms", "construct_ms", "divide_ms", "flatten_ms", "scene_create_ms"))
+    return out
+
+
+def parent(args, argv):
+    """No launcher around us: start one worker per GPU and relay rank 0's line."""
+    from raytracer_amd.launch import spawn_ranks
+    status, out = spawn_ranks([os.path.abspath(__file__)] + argv, args.gpus, timeout=3000)
+    for line in out.splitlines():
+        (sys.stdout if line.startswith("{") else sys.stderr).write(line + "\n")
+    sys.exit(status)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)  # a frame is under a millisecond; the first few dozen run before the clocks settle
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="default")
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="only the timed region and the latency pass (what the profiling scripts run)")
     ap.add_argument("--max-depth", type=int, default=5, help="diagnostic: `remaining` of primary rays (the metric uses 5)")
-    ap.add_argument("--gather", choices=["u8", "f64"], default="u8",
-                    help="N > 1: what rank 0 collects per frame: the clamped bytes the PPM prints (default) or the f64 colours")
+    ap.add_argument("--store", choices=["u8", "f64"], default="u8",
+                    help="what every rank stores (and rank 0 collects) per pixel: the clamped bytes the PPM prints "
+                         "(default) or the f64 colours")
+    ap.add_argument("--gather", choices=["u8", "f64"], default=None, help="old name of --store")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: gather each frame before rendering the next")
     ap.add_argument("--gather-mode", choices=["p2p", "collective"], default="p2p",
                     help="N > 1: grouped send/recv of exactly each rank's rows (default) or one padded dist.gather")
-    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=0,
-                    help="frames rendering at once: 2 = consecutive frames on two streams (each with its own scene "
-                         "handle and buffer), so that the next frame's wavefronts fill the GPU while the long wavefronts "
-                         "of this one finish.  Default: 1 on one GPU, 2 on several (a rank's share of the frame is then "
-                         "not much longer than its longest wavefront)")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=1,
+                    help="frames rendering at once on a GPU: 2 = consecutive frames on two streams, each with its own "
+                         "scene handle and buffer (the next frame's wavefronts fill the GPU while this frame's longest "
+                         "ones finish).  The same default, 1, at every N")
+    ap.add_argument("--single-process", action="store_true",
+                    help="N GPUs from ONE process through rt_render_multi_u8 / rt_render_multi (frame to page-locked host "
+                         "memory) instead of one process per GPU")
     args = ap.parse_args()
+    if args.gather:
+        args.store = args.gather
+
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched and not args.single_process:
+        return parent(args, sys.argv[1:])
 
     import torch
     import torch.distributed as dist
     from raytracer_amd import abi, api, scenes
 
-    world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and world_size != args.gpus:
-        raise SystemExit("--gpus %d needs a torch.distributed launch with WORLD_SIZE=%d" % (args.gpus, args.gpus))
+    world_size = int(os.environ.get("WORLD_SIZE", "1")) if not args.single_process else 1
+    rank = int(os.environ.get("RANK", "0")) if not args.single_process else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if not args.single_process else 0
+    if not args.single_process and args.gpus != world_size:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE=%d" % (args.gpus, world_size))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the render path has no CPU fallback")
     backend = os.environ.get("RT_BENCH_BACKEND", "nccl")  # "gloo" only to rehearse N > 1 on one GPU
@@ -137,28 +367,29 @@ def main():
             dist.init_process_group(backend)
     stat_dev = dev if backend == "nccl" else torch.device("cpu")
 
-    # N = 1: the single-GPU configuration (3840x2160); N > 1: the 8K frame split across ranks.
-    W = args.width or (3840 if world_size == 1 else 7680)
-    H = args.height or (2160 if world_size == 1 else 4320)
-
-    in_flight = args.in_flight or (2 if world_size > 1 and not args.no_overlap else 1)
+    W = args.width or 7680
+    H = args.height or 4320
     host = api.load()
     make_world, make_camera = scenes.WORKLOADS[args.workload]
+    if args.single_process:
+        return single_process(args, host, make_world, make_camera, W, H)
+
+    in_flight = args.in_flight
+    overlap = world_size > 1 and not args.no_overlap
     # one scene handle per frame in flight: launches on one handle must be stream-ordered
     worlds = [make_world(host) for _ in range(in_flight)]
-    world, cam = worlds[0], make_camera(host, W, H)
+    cam = make_camera(host, W, H)
     scenes_h = [host.scene_handle(w, device=local_rank) for w in worlds]
     scene = scenes_h[0]
     rows = host.local_rows(H, rank, world_size)
-    u8 = world_size > 1 and args.gather == "u8"
+    u8 = args.store == "u8"
     dtype = torch.uint8 if u8 else torch.float64
-    buffers = [torch.empty((rows, W, 3), dtype=dtype, device=dev) for _ in range(2 if world_size > 1 or in_flight > 1 else 1)]
+    buffers = [torch.empty((rows, W, 3), dtype=dtype, device=dev) for _ in range(2)]
 
     from raytracer_amd.distributed import FrameGather, OverlappedGather
     gather = FrameGather(host, W, H, rank, world_size, dev, dtype=dtype, mode=args.gather_mode) if world_size > 1 else None
     render_streams = [torch.cuda.Stream(device=dev) for _ in range(2)] if in_flight > 1 else None
-    pipe = (OverlappedGather(gather, buffers, render_streams)
-            if (gather is not None and not args.no_overlap) or in_flight > 1 else None)
+    pipe = OverlappedGather(gather, buffers, render_streams) if overlap or in_flight > 1 else None
 
     def render(buf, slot=0):
         stream = torch.cuda.current_stream().cuda_stream
@@ -167,11 +398,11 @@ def main():
 
     def step():
         if pipe is not None:
-            pipe.step(render)  # RCCL send/recv of frame k's tile buffers overlaps the render of frame k + 1
+            pipe.step(render)  # the exchange of frame k's tile buffers overlaps the render of frame k + 1
         else:
             render(buffers[0])
             if gather is not None:
-                gather(buffers[0])  # RCCL send/recv of the compact tile buffers to rank 0, rows into frame order
+                gather(buffers[0])
 
     def sync():
         torch.cuda.synchronize()  # all streams of this device, the gather's side stream included
@@ -179,6 +410,7 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # ---- the timed region ----------------------------------------------------------------------------
     for _ in range(args.warmup):
         step()
     sync()
@@ -187,29 +419,63 @@ def main():
         step()
     sync()
     elapsed = time.perf_counter() - t0
-
-    # kernel device times of the timed launches, from HIP events on the launch stream
-    cap = min(args.steps, 256)
-    ms = (ctypes.c_float * cap)()
-    got = host.abi.rt_scene_launch_times(scene, ms, min(cap, max(args.steps // in_flight, 1)))
-    kernel_ms = sum(ms[i] for i in range(got)) / max(got, 1)
+    per_scene = max(args.steps // in_flight, 1)
+    timed_ms = launch_times(host, scene, per_scene)
+    kernel_ms_timed = sum(timed_ms) / max(len(timed_ms), 1)
     st = abi.rt_stats()
     host.abi.rt_scene_ray_counts(scene, ctypes.byref(st))
     rays_local = st.total_rays()
 
-    t = torch.tensor([elapsed, kernel_ms, float(rays_local)], dtype=torch.float64, device=stat_dev)
+    # ---- one frame at a time, nothing overlapped: latency and its parts ---------------------------
+    L = max(2, min(args.steps, 30))
+    lat = []
+    g_events = []
+    for _ in range(L):
+        sync()
+        t = time.perf_counter()
+        render(buffers[0])
+        if gather is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gather(buffers[0])
+            e1.record()
+            g_events.append((e0, e1))
+        torch.cuda.synchronize()
+        lat.append((time.perf_counter() - t) * 1e3)
+    clean_ms = launch_times(host, scene, L)
+    kernel_ms = sum(clean_ms) / max(len(clean_ms), 1)
+    latency_ms = sum(lat) / len(lat)
+    gather_ms = sum(a.elapsed_time(b) for a, b in g_events) / len(g_events) if g_events else 0.0
+    d2h_ms = 0.0
+    if rank == 0:
+        frame = gather.frame if gather is not None else buffers[0]
+        pinned = torch.empty(frame.shape, dtype=frame.dtype, pin_memory=True)
+        pinned.copy_(frame, non_blocking=True)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            pinned.copy_(frame, non_blocking=True)
+        e1.record()
+        torch.cuda.synchronize()
+        d2h_ms = e0.elapsed_time(e1) / 5
+        del pinned
+
+    t = torch.tensor([elapsed, kernel_ms, kernel_ms_timed, float(rays_local)], dtype=torch.float64, device=stat_dev)
     if world_size > 1:
         tmax = t.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         tsum = t.clone()
         dist.all_reduce(tsum, op=dist.ReduceOp.SUM)
-        elapsed, kernel_ms, rays = float(tmax[0]), float(tmax[1]), float(tsum[2])
+        elapsed, kernel_ms, kernel_ms_timed, rays = float(tmax[0]), float(tmax[1]), float(tmax[2]), float(tsum[3])
     else:
         rays = float(rays_local)
 
     if rank == 0:
         work = load_work(args.workload, W, H) if args.max_depth == 5 else None
         ms_per_step = elapsed / args.steps * 1e3
+        exchange = ("RCCL" if backend == "nccl" else backend) + " " + (
+            "grouped send/recv" if args.gather_mode == "p2p" else "gather")
         out = {
             "metric": "Mrays/s (primary+secondary), %s scene %dx%d" % (args.workload, W, H),
             "value": rays * args.steps / elapsed / 1e6,
@@ -219,56 +485,82 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong" if world_size > 1 else "weak",
+            "scaling": "strong",  # the frame is the same at every N
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": "%s scene%s, %dx%d, depth %d" % (
+                "workload": "%s scene%s, %dx%d, depth %d, %s frame store" % (
                     args.workload, " (src/lib.rs build_world)" if args.workload == "default" else " (raytracer_amd/scenes.py)",
-                    W, H, args.max_depth),
+                    W, H, args.max_depth, "clamped u8" if u8 else "f64"),
                 "rays_per_frame": int(rays),
                 "partition": "cyclic 8-row tiles over %d rank(s)%s" % (
                     world_size,
-                    ", RCCL gather of %s rows to rank 0%s" % (
-                        "clamped u8" if u8 else "f64", "" if args.no_overlap else ", overlapped with the next frame's render")
-                    if world_size > 1 else "") + (", %d frames in flight on separate streams" % in_flight if in_flight > 1 else ""),
+                    ", %s of %s rows to rank 0%s" % (exchange, "clamped u8" if u8 else "f64",
+                                                    ", overlapped with the next frame's render" if overlap else "")
+                    if world_size > 1 else ""),
+                "frames_in_flight": in_flight,
             },
-            "kernel_ms": kernel_ms,  # mean launch duration; with 2 frames in flight launches overlap and each takes longer
-            "frames_in_flight": in_flight,
+            # one frame at a time, nothing overlapped (mean of %d frames after the timed region)
+            "frame_latency_ms": latency_ms,
+            "kernel_ms": kernel_ms,        # mean launch duration (HIP events), longest rank
+            "gather_ms": gather_ms,        # rank 0: exchange + placing the rows (device time)
+            "d2h_ms": d2h_ms,              # rank 0: the assembled frame to page-locked host memory
+            "latency_frames": L,
+            "kernel_ms_in_timed_region": kernel_ms_timed,
         }
         if work is not None:
-            flops = float(work["flops"])
-            # with two frames in flight a launch shares the GPU with its neighbour for most of its life:
-            # the rate is then what the GPU sustains over the timed region, not flops / one launch's duration
-            per_frame_ms = ms_per_step if in_flight > 1 else kernel_ms
-            achieved = flops / world_size / (per_frame_ms * 1e-3) / 1e12 if per_frame_ms > 0 else 0.0
-            out["roofline"] = {
-                "bound": "valu-fp64",
-                "achieved": achieved,
-                "peak": FP64_VECTOR_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-                "traffic": load_traffic(args.workload, W, H) if world_size == 1 else None,
-                "peak_without_fma": FP64_VECTOR_PEAK_TFLOPS / 2,
-                "frac_without_fma": achieved / (FP64_VECTOR_PEAK_TFLOPS / 2),
-                "algorithmic_flops_per_launch": flops / world_size,
-                "oracle_rays_per_frame": work["rays"],
-            }
-            # the secondary roof: the only streamed bytes are the frame itself (scene tables stay in cache)
             frame_bytes = rows * W * 3 * (1 if u8 else 8)
-            traffic = out["roofline"]["traffic"]
-            out["roofline"]["hbm"] = {
-                "peak_gbs": HBM_PEAK_GBS,
-                "algorithmic_bytes_per_launch": frame_bytes,
-                "algorithmic_gbs": frame_bytes / (per_frame_ms * 1e-3) / 1e9 if per_frame_ms > 0 else 0.0,
-                "measured_gbs": traffic / (per_frame_ms * 1e-3) / 1e9 if traffic and per_frame_ms > 0 else None,
-            }
-        if world_size == 1 and not args.no_cpu_baseline:
+            out["roofline"] = roofline_block(work, load_pmc(args.workload, W, H) if world_size == 1 else None,
+                                             float(work["flops"]) / world_size, kernel_ms, frame_bytes, W, H)
+            out["roofline"]["oracle_rays_per_frame"] = work["rays"]
+        if world_size == 1 and args.workload == "default" and not args.no_extras:
+            host.reset()
+            out["single_gpu_4k"] = single_gpu_4k(host, torch, dev, local_rank)
+            host.reset()
+            out["e2e"] = e2e_block(host, torch, dev, local_rank)
+            host.reset()
+            out["scene_build"] = scene_build_block(host, local_rank)
+            host.reset()
+        if world_size == 1 and not args.no_cpu_baseline and not args.no_extras:
             out["cpu_baseline"] = cpu_baseline(args.workload, W, H)
         print(json.dumps(out))
     if world_size > 1:
         dist.destroy_process_group()
+
+
+def single_process(args, host, make_world, make_camera, W, H):
+    """N GPUs from one process: rt_multi_create + rt_render_multi(_u8) into page-locked host memory."""
+    import numpy as np
+    n = args.gpus
+    world, cam = make_world(host), make_camera(host, W, H)
+    multi = host.multi(world, n)
+    u8 = args.store == "u8"
+    out_arr = host.pinned_empty((H, W, 3), np.uint8 if u8 else np.float64)
+    for _ in range(args.warmup):
+        multi.render(cam, max_depth=args.max_depth, out=out_arr.array, u8=u8)
+    t0 = time.perf_counter()
+    parts = []
+    for _ in range(args.steps):
+        _, st = multi.render(cam, max_depth=args.max_depth, out=out_arr.array, u8=u8, stats=True)
+        parts.append((st.kernel_ms, st.exchange_ms, st.total_ms))
+    elapsed = time.perf_counter() - t0
+    rays = st.total_rays()
+    mean = lambda k: sum(p[k] for p in parts) / len(parts)
+    print(json.dumps({
+        "metric": "Mrays/s (primary+secondary), %s scene %dx%d" % (args.workload, W, H),
+        "value": rays * args.steps / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "%s scene, %dx%d, depth %d, %s frame to page-locked HOST memory" % (
+                       args.workload, W, H, args.max_depth, "clamped u8" if u8 else "f64"),
+                   "rays_per_frame": int(rays),
+                   "partition": "cyclic 8-row tiles over %d GPU(s) of ONE process (rt_render_multi%s): every GPU copies its "
+                                "tiles over its own PCIe link" % (n, "_u8" if u8 else "")},
+        "kernel_ms": mean(0), "download_ms": mean(1), "call_ms": mean(2),
+    }))
+    out_arr.close()
+    multi.close()
 
 
 if __name__ == "__main__":

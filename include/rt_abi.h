@@ -148,6 +148,16 @@ int rt_device_count(void);
 int rt_scene_create(const rt_scene_desc* desc, int device, rt_scene** out);
 void rt_scene_destroy(rt_scene* scene);
 
+/* What rt_scene_create spent on a scene (host clock, ms) and what it built.  No counterpart in the
+ * reference, whose scene graph is walked as it is (src/geometry/group.rs:133-154). */
+typedef struct rt_build_info {
+    float validate_ms; /* checking the tables */
+    float records_ms;  /* laying the node table out as traversal and shading records (cull boxes, sorting) */
+    float upload_ms;   /* device allocations and copies */
+    int32_t n_nodes, n_records, n_cull_records;
+} rt_build_info;
+int rt_scene_build_info(const rt_scene* scene, rt_build_info* out);
+
 /* Rows of the frame that `params->rank` renders (the compact buffer height). */
 int64_t rt_local_rows(int32_t height, const rt_params* params);
 /* Frame row stored at compact row `local_row` of `params->rank`. */
@@ -169,7 +179,10 @@ int rt_render_device(rt_scene* scene, const rt_camera* camera, const rt_params* 
  * after it reports this call's rays until the next launch on the GPU. */
 int rt_render_device_static(rt_scene* scene, const rt_camera* camera, const rt_params* params,
                             double* d_rgb, void* hip_stream);
-/* Same as rt_render_device, but synchronous into HOST memory; fills stats when not NULL. */
+/* Same as rt_render_device, but synchronous into HOST memory; fills stats when not NULL.  The
+ * frame crosses PCIe once: straight into rgb_out when that is page-locked memory (rt_host_alloc,
+ * hipHostMalloc, hipHostRegister), else through a ring of page-locked slots that host threads empty
+ * into rgb_out while the next slot fills. */
 int rt_render(rt_scene* scene, const rt_camera* camera, const rt_params* params, double* rgb_out,
               rt_stats* stats);
 /* render followed by Canvas::clamp on every channel (src/canvas.rs:50-60: 255*c saturated to
@@ -197,11 +210,50 @@ int rt_ppm_encode(int device, const uint8_t* rgb8, int32_t width, int32_t height
 int rt_color_at(rt_scene* scene, int64_t n, const double* origins, const double* directions,
                 int32_t remaining, double* rgb_out, rt_stats* stats);
 
+/* Page-locked host memory, which the GPU writes directly: a frame buffer taken from here makes
+ * rt_render, rt_render_u8, rt_render_ppm and rt_render_multi* skip the staging ring.  No counterpart
+ * in the reference (its Canvas is ordinary memory, src/window/canvas.rs:8-12).  NULL on failure. */
+void* rt_host_alloc(uint64_t bytes);
+void rt_host_free(void* p);
+
 /* After the stream has been synchronised: device times (ms) of the most recent launches on this
  * scene, oldest first, at most `cap`; returns how many were written. */
 int rt_scene_launch_times(rt_scene* scene, float* ms, int cap);
 /* Ray counters of the most recent launch (synchronises the launch's stream). */
 int rt_scene_ray_counts(rt_scene* scene, rt_stats* stats);
+
+/* ---- one frame on several GPUs from one call ------------------------------------------------------
+ * render (src/lib.rs:77-133) is ONE call that fans the pixels out to its workers and collects them
+ * again (lib.rs:85-126).  rt_multi does the same over the GPUs of one process: it owns a copy of the
+ * scene on every GPU it uses, renders tile t (RT_TILE rows) on rank t % n_ranks, and assembles the
+ * frame.  One call at a time per handle. */
+typedef struct rt_multi rt_multi;
+typedef struct rt_multi_stats {
+    uint64_t rays_primary, rays_shadow, rays_reflect, rays_refract; /* summed over the ranks */
+    float kernel_ms;      /* longest render launch over the ranks (device time, HIP events) */
+    float render_wall_ms; /* host clock: from the call to the end of the longest render (host variants: estimated
+                             as kernel_ms after the call began; the first downloads overlap the last renders) */
+    float exchange_ms;    /* host variants: from there until the last byte is in host memory; device variant:
+                             device time of the gather on rank 0's GPU */
+    float total_ms;       /* host clock around the whole call */
+} rt_multi_stats;
+/* devices: n_ranks HIP ordinals, or NULL for 0 .. n_ranks-1.  An ordinal may repeat: those ranks then
+ * share a GPU (each with its own scene copy, stream and buffer), which is how the partition and the
+ * assembly are exercised on a machine with one GPU. */
+int rt_multi_create(const rt_scene_desc* desc, int32_t n_ranks, const int32_t* devices, rt_multi** out);
+void rt_multi_destroy(rt_multi* multi);
+int32_t rt_multi_ranks(const rt_multi* multi);
+/* The whole frame into HOST memory (width * height * 3 doubles / bytes, row-major): every GPU copies
+ * its own tiles over its own PCIe link to their rows of the frame. */
+int rt_render_multi(rt_multi* multi, const rt_camera* camera, int32_t max_depth, double* rgb_out,
+                    rt_multi_stats* stats);
+int rt_render_multi_u8(rt_multi* multi, const rt_camera* camera, int32_t max_depth, uint8_t* rgb8_out,
+                       rt_multi_stats* stats);
+/* The whole frame into DEVICE memory on rank 0's GPU (u8 != 0: clamped bytes, else doubles): rank 0's
+ * GPU pulls every peer's tiles over xGMI (peer-mapped reads, all links at once) and writes the rows in
+ * frame order.  Synchronous. */
+int rt_render_multi_device(rt_multi* multi, const rt_camera* camera, int32_t max_depth, void* d_frame,
+                           int32_t u8, rt_multi_stats* stats);
 
 /* Device self-test with no counterpart in the reference: the kernel divides by a ray direction
  * through its precomputed reciprocal (one exact correction step) instead of a full division per

@@ -13,6 +13,9 @@ RT_TILE = 8
 RT_STATIC_MAX_TILES = 1 << 19
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_LIMIT, RT_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 RT_NODE_CASTS_SHADOW, RT_NODE_CLOSED = 1, 2
+RT_MAX_CSG_NEST = 4
+RT_MAX_CSG_HITS = 24
+RT_NODE_CSG_DIFFERENCE, RT_NODE_CSG_INTERSECTION, RT_NODE_CSG_UNION, RT_NODE_CSG_OP_MASK = 0 << 4, 1 << 4, 2 << 4, 3 << 4
 
 c_d = C.c_double
 i32 = C.c_int32
@@ -86,11 +89,26 @@ class rt_stats(C.Structure):
         return self.rays_primary + self.rays_shadow + self.rays_reflect + self.rays_refract
 
 
+class rt_build_info(C.Structure):
+    _fields_ = [("validate_ms", C.c_float), ("records_ms", C.c_float), ("upload_ms", C.c_float),
+                ("n_nodes", i32), ("n_records", i32), ("n_cull_records", i32)]
+
+
+class rt_multi_stats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
+                ("rays_refract", C.c_uint64), ("kernel_ms", C.c_float), ("render_wall_ms", C.c_float),
+                ("exchange_ms", C.c_float), ("total_ms", C.c_float)]
+
+    def total_rays(self):
+        return self.rays_primary + self.rays_shadow + self.rays_reflect + self.rays_refract
+
+
 # Every entry point include/rt_abi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "rt_device_count": (C.c_int, []),
     "rt_scene_create": (C.c_int, [C.POINTER(rt_scene_desc), C.c_int, C.POINTER(C.c_void_p)]),
     "rt_scene_destroy": (None, [C.c_void_p]),
+    "rt_scene_build_info": (C.c_int, [C.c_void_p, C.POINTER(rt_build_info)]),
     "rt_local_rows": (C.c_int64, [i32, C.POINTER(rt_params)]),
     "rt_global_row": (C.c_int64, [C.c_int64, C.POINTER(rt_params)]),
     "rt_render_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), C.POINTER(rt_params), C.c_void_p,
@@ -109,6 +127,16 @@ SYMBOLS = {
                                 C.POINTER(C.c_uint64)]),
     "rt_color_at": (C.c_int, [C.c_void_p, C.c_int64, C.POINTER(c_d), C.POINTER(c_d), i32, C.POINTER(c_d),
                               C.POINTER(rt_stats)]),
+    "rt_multi_create": (C.c_int, [C.POINTER(rt_scene_desc), i32, C.POINTER(i32), C.POINTER(C.c_void_p)]),
+    "rt_multi_destroy": (None, [C.c_void_p]),
+    "rt_multi_ranks": (i32, [C.c_void_p]),
+    "rt_render_multi": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), i32, C.POINTER(c_d), C.POINTER(rt_multi_stats)]),
+    "rt_render_multi_u8": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), i32, C.POINTER(C.c_uint8),
+                                     C.POINTER(rt_multi_stats)]),
+    "rt_render_multi_device": (C.c_int, [C.c_void_p, C.POINTER(rt_camera), i32, C.c_void_p, i32,
+                                         C.POINTER(rt_multi_stats)]),
+    "rt_host_alloc": (C.c_void_p, [C.c_uint64]),
+    "rt_host_free": (None, [C.c_void_p]),
     "rt_scene_launch_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int]),
     "rt_scene_ray_counts": (C.c_int, [C.c_void_p, C.POINTER(rt_stats)]),
     "rt_selftest_division": (C.c_int, [C.c_int, C.c_int64, C.POINTER(c_d), C.POINTER(c_d), C.POINTER(c_d),

@@ -164,6 +164,16 @@ class HostApi(Api):
                                         C.byref(st)))
         return (out, st) if stats else out
 
+    # ---- several GPUs from one process -----------------------------------------------------------
+    def multi(self, world, n_ranks, devices=None):
+        """One handle that owns a copy of `world` on every GPU it uses (rt_multi_create).  devices:
+        HIP ordinals per rank (may repeat), default 0 .. n_ranks-1."""
+        return Multi(self, world, n_ranks, devices)
+
+    def pinned_empty(self, shape, dtype):
+        """A numpy array in page-locked host memory (rt_host_alloc): the GPU writes it directly."""
+        return PinnedArray(self, shape, dtype)
+
     def local_rows(self, height, rank, world_size):
         prm = abi.rt_params(0, rank, world_size, 0)
         return int(self.abi.rt_local_rows(height, C.byref(prm)))
@@ -191,6 +201,91 @@ class HostApi(Api):
         buf = C.create_string_buffer(n)
         self._f("ppm_copy")(buf)
         return buf.raw[:n]
+
+
+class PinnedArray:
+    """Owns one rt_host_alloc block; `.array` is the numpy view.  Freed by close() or with the object."""
+
+    def __init__(self, host, shape, dtype):
+        self.host = host
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        self.ptr = host.abi.rt_host_alloc(max(n, 1))
+        if not self.ptr:
+            raise abi.RtError(abi.RT_ERR_HIP, (host.abi.rt_last_error() or b"").decode())
+        buf = (C.c_char * max(n, 1)).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            self.host.abi.rt_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Multi:
+    """render (src/lib.rs:77-133) over several GPUs of this process: rt_multi_create and the
+    rt_render_multi* entry points."""
+
+    def __init__(self, host, world, n_ranks, devices=None):
+        self.host = host
+        self.world = world  # keeps the tables alive while the handle is created
+        desc = host.scene_desc(world)
+        dev = None
+        if devices is not None:
+            assert len(devices) == n_ranks
+            dev = (C.c_int32 * n_ranks)(*[int(d) for d in devices])
+        self.h = C.c_void_p()
+        rc = host.abi.rt_multi_create(C.byref(desc), n_ranks, dev, C.byref(self.h))
+        if rc != 0:
+            raise abi.RtError(rc, (host.abi.rt_last_error() or b"").decode())
+        self.n_ranks = n_ranks
+
+    def _check(self, rc):
+        if rc != 0:
+            raise abi.RtError(rc, (self.host.abi.rt_last_error() or b"").decode())
+
+    def render(self, camera, max_depth=5, out=None, u8=False, stats=False):
+        """The whole frame in host memory -> (H, W, 3) float64, or uint8 with u8=True.  `out`: an
+        array to fill (for example PinnedArray.array)."""
+        cam = self.host.camera_block(camera)
+        dtype = np.uint8 if u8 else np.float64
+        if out is None:
+            out = np.empty((cam.height, cam.width, 3), dtype=dtype)
+        assert out.shape == (cam.height, cam.width, 3) and out.dtype == dtype and out.flags.c_contiguous
+        st = abi.rt_multi_stats()
+        if u8:
+            self._check(self.host.abi.rt_render_multi_u8(self.h, C.byref(cam), max_depth,
+                                                         out.ctypes.data_as(C.POINTER(C.c_uint8)), C.byref(st)))
+        else:
+            self._check(self.host.abi.rt_render_multi(self.h, C.byref(cam), max_depth, out.ctypes.data_as(c_dp),
+                                                      C.byref(st)))
+        return (out, st) if stats else out
+
+    def render_device(self, camera, d_ptr, max_depth=5, u8=False):
+        """The whole frame in device memory at d_ptr on rank 0's GPU; returns the stats."""
+        cam = self.host.camera_block(camera)
+        st = abi.rt_multi_stats()
+        self._check(self.host.abi.rt_render_multi_device(self.h, C.byref(cam), max_depth, C.c_void_p(d_ptr),
+                                                         1 if u8 else 0, C.byref(st)))
+        return st
+
+    def close(self):
+        if self.h:
+            self.host.abi.rt_multi_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 _API = None

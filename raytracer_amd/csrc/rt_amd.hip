@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "rt_abi.h"
+#include "rt_download.h"
 
 #pragma clang fp contract(off)
 
@@ -1769,6 +1770,10 @@ struct rt_scene {
     hipEvent_t ev_stop[TIMING_RING] = {};
     long long launches = 0;
     hipStream_t last_stream = nullptr;
+    rt_build_info build{};         // what rt_scene_create spent and produced
+    rtdl::Downloader dl;           // frames to caller memory (the synchronous entry points)
+    bool dl_ready = false;
+    hipEvent_t frame_done = nullptr;  // the staging frame is complete
 };
 
 namespace {
@@ -1796,12 +1801,15 @@ int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
         return fail(RT_ERR_INVALID, "null table with non-zero size");
     if (d->n_lights > RT_MAX_LIGHTS) return fail(RT_ERR_LIMIT, "more than RT_MAX_LIGHTS lights");
     all_cast = true;
+    std::vector<int> open;  // the containers around node i, outermost first (nodes are in pre-order)
     for (int i = 0; i < d->n_nodes; ++i) {
         const rt_node& n = d->nodes[i];
         auto bad = [&](const char* what) {
             return fail(RT_ERR_INVALID, "node " + std::to_string(i) + ": " + what);
         };
         if (n.type < RT_GROUP || n.type > RT_CSG) return bad("unknown type");
+        while (!open.empty() && d->nodes[open.back()].skip <= i) open.pop_back();
+        if (n.parent != (open.empty() ? -1 : open.back())) return bad("parent is not the nearest enclosing group or CSG shape");
         const bool container = n.type == RT_GROUP || n.type == RT_CSG;
         if (n.parent < -1 || n.parent >= i) return bad("parent must precede the node");
         if (n.parent >= 0 && d->nodes[n.parent].type != RT_GROUP && d->nodes[n.parent].type != RT_CSG)
@@ -1863,6 +1871,8 @@ int validate(const rt_scene_desc* d, bool& all_cast, bool& any_transparent) {
         if (!container) {
             if (n.material < 0 || n.material >= d->n_materials) return bad("material out of range");
             if (!(n.flags & RT_NODE_CASTS_SHADOW)) all_cast = false;
+        } else {
+            open.push_back(i);
         }
     }
     any_transparent = false;
@@ -2011,12 +2021,18 @@ void node_boxes(const rt_scene_desc* d, std::vector<NodeBox>& box, std::vector<c
             if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) b.ok = false;
         double fwd[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
         if (b.ok && n.xform >= 0 && !affine_forward(d->xforms[n.xform].inv, fwd)) b.ok = false;
-        double smin = INFINITY, smax = 0.0;
-        for (int k = 0; k < 3; ++k) {
-            const double col = std::sqrt(fwd[k] * fwd[k] + fwd[4 + k] * fwd[4 + k] + fwd[8 + k] * fwd[8 + k]);
-            smin = std::fmin(smin, col);
-            smax = std::fmax(smax, col);
-        }
+        // Bounds on the stretch of the object-to-here map that hold for any affine map (shear, scale
+        // after rotation): its largest singular value is at most the Frobenius norm of its 3x3, its
+        // smallest at least 1 / the Frobenius norm of the inverse's 3x3.  (Column norms are the
+        // singular values only for a rotation times a scale.)
+        double fro_fwd = 0.0, fro_inv = 0.0;
+        for (int row = 0; row < 3; ++row)
+            for (int k = 0; k < 3; ++k) {
+                fro_fwd += fwd[row * 4 + k] * fwd[row * 4 + k];
+                const double v = n.xform >= 0 ? d->xforms[n.xform].inv[row * 4 + k] : (row == k ? 1.0 : 0.0);
+                fro_inv += v * v;
+            }
+        const double smax = std::sqrt(fro_fwd), smin = 1.0 / std::sqrt(fro_inv);
         b.far = below * smax / (smin * smin);
         if (!(smin > 0.0) || !std::isfinite(b.far)) b.ok = false;
         if (b.ok) {
@@ -2517,6 +2533,8 @@ int fill_stats(rt_scene* s, rt_stats* st) {
 extern "C" {
 
 const char* rt_last_error(void) { return g_error.c_str(); }
+// For the other source files of this library (not part of the ABI).
+void rt_internal_set_error(const char* message) { g_error = message ? message : ""; }
 
 int rt_device_count(void) {
     int n = 0;
@@ -2528,8 +2546,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (!out) return fail(RT_ERR_INVALID, "null out pointer");
     *out = nullptr;
     bool all_cast = true, any_transparent = false;
+    const double t_start = rtdl::now_ms();
     int rc = validate(d, all_cast, any_transparent);
     if (rc != RT_OK) return rc;
+    const double t_validated = rtdl::now_ms();
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
@@ -2545,12 +2565,20 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         rt_scene_destroy(s);
         return code;
     };
+    double records_ms = 0.0;
     {
+        const double t0 = rtdl::now_ms();
         std::vector<SRec> srecs = build_shade_records(d);
+        records_ms += rtdl::now_ms() - t0;
         if ((rc = upload(s, srecs.data(), srecs.size(), &s->dev.shade)) != RT_OK) return cleanup(rc);
     }
     {
+        const double t0 = rtdl::now_ms();
         std::vector<TRec> recs = build_records(d);
+        records_ms += rtdl::now_ms() - t0;
+        s->build.n_records = (int32_t)recs.size();
+        for (const TRec& r : recs)
+            if ((r.kind & 0xff) == T_CULL) ++s->build.n_cull_records;
         if ((rc = upload(s, recs.data(), recs.size(), &s->dev.trav)) != RT_OK) return cleanup(rc);
         s->dev.n_trav = (int)recs.size();
         bool cls[3] = {false, false, false};
@@ -2593,7 +2621,18 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         if (hipEventCreate(&s->ev_start[i]) != hipSuccess || hipEventCreate(&s->ev_stop[i]) != hipSuccess)
             return cleanup(fail(RT_ERR_HIP, "hipEventCreate failed"));
     }
+    HIP_TRY(hipDeviceSynchronize());
+    s->build.validate_ms = (float)(t_validated - t_start);
+    s->build.records_ms = (float)records_ms;
+    s->build.upload_ms = (float)(rtdl::now_ms() - t_validated - records_ms);  // allocations, copies, events
+    s->build.n_nodes = d->n_nodes;
     *out = s;
+    return RT_OK;
+}
+
+int rt_scene_build_info(const rt_scene* s, rt_build_info* out) {
+    if (!s || !out) return fail(RT_ERR_INVALID, "bad arguments");
+    *out = s->build;
     return RT_OK;
 }
 
@@ -2606,6 +2645,8 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->d_order) (void)hipFree(s->d_order);
     if (s->d_frame) (void)hipFree(s->d_frame);
     if (s->d_rays) (void)hipFree(s->d_rays);
+    if (s->dl_ready) s->dl.destroy();
+    if (s->frame_done) (void)hipEventDestroy(s->frame_done);
     for (int i = 0; i < TIMING_RING; ++i) {
         if (s->ev_start[i]) (void)hipEventDestroy(s->ev_start[i]);
         if (s->ev_stop[i]) (void)hipEventDestroy(s->ev_stop[i]);
@@ -2682,28 +2723,51 @@ int rt_render_device_static(rt_scene* s, const rt_camera* cam, const rt_params* 
     return render_device(s, cam, prm, d_rgb, false, hip_stream, true);
 }
 
+// Grows the scene's staging frame to `bytes` (device memory).
+static int reserve_frame(rt_scene* s, size_t bytes) {
+    if (bytes <= s->frame_bytes) return RT_OK;
+    if (s->d_frame) (void)hipFree(s->d_frame);
+    s->d_frame = nullptr;
+    s->frame_bytes = 0;
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, bytes));
+    s->d_frame = (double*)p;
+    s->frame_bytes = bytes;
+    return RT_OK;
+}
+// The copy stream and the "frame complete" event of the synchronous entry points, made on first use.
+static int ready_downloader(rt_scene* s) {
+    if (!s->dl_ready) {
+        HIP_TRY(s->dl.init(s->device));
+        s->dl_ready = true;
+    }
+    if (!s->frame_done) HIP_TRY(hipEventCreateWithFlags(&s->frame_done, hipEventDisableTiming));
+    return RT_OK;
+}
+
 static int render_host(rt_scene* s, const rt_camera* cam, const rt_params* prm, void* out, bool out_u8,
                        rt_stats* stats) {
     if (!s || !cam) return fail(RT_ERR_INVALID, "null scene or camera");
     int rc = check_params(prm);
     if (rc != RT_OK) return rc;
-    int64_t rows = rt_local_rows(cam->height, prm);
-    size_t bytes = (size_t)rows * (size_t)cam->width * 3 * (out_u8 ? 1 : sizeof(double));
+    if (cam->width <= 0 || cam->height <= 0) return fail(RT_ERR_INVALID, "empty canvas");
+    const int64_t rows = rt_local_rows(cam->height, prm);
+    if (rows < 0) return fail(RT_ERR_INVALID, "bad canvas height");
+    const size_t pixel = out_u8 ? 3 : 3 * sizeof(double);
+    const size_t row_bytes = (size_t)cam->width * pixel;
+    if (rows > 0 && row_bytes > SIZE_MAX / (size_t)rows) return fail(RT_ERR_LIMIT, "frame size overflows");
+    const size_t bytes = (size_t)rows * row_bytes;
     if (bytes && !out) return fail(RT_ERR_INVALID, "null output buffer");
     HIP_TRY(hipSetDevice(s->device));
-    if (bytes > s->frame_bytes) {
-        if (s->d_frame) HIP_TRY(hipFree(s->d_frame));
-        s->d_frame = nullptr;
-        s->frame_bytes = 0;
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, bytes));
-        s->d_frame = (double*)p;
-        s->frame_bytes = bytes;
-    }
+    if ((rc = reserve_frame(s, bytes)) != RT_OK) return rc;
+    if ((rc = ready_downloader(s)) != RT_OK) return rc;
     rc = render_device(s, cam, prm, s->d_frame, out_u8, nullptr);
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipStreamSynchronize(nullptr));
-    if (bytes) HIP_TRY(hipMemcpy(out, s->d_frame, bytes, hipMemcpyDeviceToHost));
+    HIP_TRY(hipEventRecord(s->frame_done, nullptr));
+    // The frame crosses PCIe on the copy stream: straight into page-locked memory, or through the
+    // page-locked ring when the caller's buffer is ordinary memory (rt_download.h).
+    HIP_TRY(s->dl.download(reinterpret_cast<const char*>(s->d_frame), bytes, 0, 0, 1, static_cast<char*>(out),
+                           s->frame_done));
     return fill_stats(s, stats);
 }
 
@@ -2840,15 +2904,8 @@ int rt_render_ppm(rt_scene* s, const rt_camera* cam, const rt_params* prm, char*
     const size_t frame = (size_t)cam->width * cam->height * 3;
     const size_t work = ((size_t)cam->height + 1) * sizeof(unsigned long long);
     const size_t need = ((frame + 255) & ~(size_t)255) + ((work + 255) & ~(size_t)255) + (capacity ? capacity : 1);
-    if (need > s->frame_bytes) {
-        if (s->d_frame) HIP_TRY(hipFree(s->d_frame));
-        s->d_frame = nullptr;
-        s->frame_bytes = 0;
-        void* p = nullptr;
-        HIP_TRY(hipMalloc(&p, need));
-        s->d_frame = (double*)p;
-        s->frame_bytes = need;
-    }
+    if ((rc = reserve_frame(s, need)) != RT_OK) return rc;
+    if ((rc = ready_downloader(s)) != RT_OK) return rc;
     uint8_t* d_rgb8 = reinterpret_cast<uint8_t*>(s->d_frame);
     unsigned long long* d_work = reinterpret_cast<unsigned long long*>(d_rgb8 + ((frame + 255) & ~(size_t)255));
     char* d_text = reinterpret_cast<char*>(d_work) + ((work + 255) & ~(size_t)255);
@@ -2858,8 +2915,23 @@ int rt_render_ppm(rt_scene* s, const rt_camera* cam, const rt_params* prm, char*
     rc = ppm_encode_device(d_rgb8, cam->width, cam->height, d_text, capacity, d_work, &total, nullptr);
     *length = total;
     if (rc != RT_OK) return rc;
-    HIP_TRY(hipMemcpy(text_out, d_text, (size_t)total, hipMemcpyDeviceToHost));
+    HIP_TRY(hipEventRecord(s->frame_done, nullptr));
+    HIP_TRY(s->dl.download(d_text, (size_t)total, 0, 0, 1, text_out, s->frame_done));
     return fill_stats(s, stats);
+}
+
+void* rt_host_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? (size_t)bytes : 1, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        g_error = "hipHostMalloc failed";
+        return nullptr;
+    }
+    return p;
+}
+
+void rt_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
 }
 
 int rt_scene_launch_times(rt_scene* s, float* ms, int cap) {

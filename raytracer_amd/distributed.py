@@ -18,21 +18,27 @@ import torch.distributed as dist
 
 
 class FrameGather:
-    def __init__(self, host, width, height, rank, world_size, device, dst=0, dtype=torch.float64, mode="p2p"):
+    def __init__(self, host, width, height, rank, world_size, device, dst=0, dtype=torch.float64, mode="p2p",
+                 frames=2):
         """mode "p2p": grouped send/recv, each rank sends exactly its rows.  mode "collective": one
         dist.gather of buffers padded to the largest rank's row count (a plain collective, for
-        stacks where grouped point-to-point is not available)."""
+        stacks where grouped point-to-point is not available).  frames: how many assembled frames
+        rank dst keeps; call k writes frame k % frames, so a consumer may still read frame k while
+        frame k + 1 is being assembled."""
         self.rank, self.world_size, self.dst = rank, world_size, dst
         self.dtype = dtype
         self.mode = mode
         self.padded = None
         self.width, self.height = width, height
         self.rows = [host.local_rows(height, r, world_size) for r in range(world_size)]
-        self.frame = None
+        self.frame = None   # the frame the most recent call assembled
+        self.frames = None
+        self.calls = 0
         self.parts = None
         self.index = None
         if rank == dst:
-            self.frame = torch.empty((height, width, 3), dtype=dtype, device=device)
+            self.frames = [torch.empty((height, width, 3), dtype=dtype, device=device) for _ in range(max(1, frames))]
+            self.frame = self.frames[0]
             # the peers' rows arrive in slices of one staging buffer, so that a single index_copy_
             # puts them all in frame order (one launch per frame instead of one per peer)
             others = [r for r in range(world_size) if r != dst]
@@ -49,6 +55,9 @@ class FrameGather:
     def __call__(self, local):
         """local: this rank's (rows, W, 3) tensor.  Returns the full frame on rank dst."""
         assert tuple(local.shape) == (self.rows[self.rank], self.width, 3) and local.dtype == self.dtype
+        if self.frames is not None:
+            self.frame = self.frames[self.calls % len(self.frames)]
+        self.calls += 1
         if self.world_size > 1 and local.is_cuda and dist.get_backend() == "gloo":
             return self._staged(local)  # rehearsal only: gloo moves host memory
         if self.world_size > 1 and self.mode == "collective":
@@ -105,8 +114,10 @@ class OverlappedGather:
     into the other buffer.  With `render_streams` (one per buffer) consecutive frames also render on
     different streams, so the wavefronts of frame k + 1 fill the GPU while the last long wavefronts
     of frame k finish; each buffer then needs its own scene handle, because launches on one scene
-    must be stream-ordered.  On CPU tensors (tests) it degrades to render then gather.  The frame
-    returned by step() is complete once `wait()` has returned."""
+    must be stream-ordered.  On CPU tensors (tests) it degrades to render then gather.  step()
+    returns the assembled frame (rank dst) and, on CUDA, sets `self.frame_done` to the event after
+    which it is complete; the gather alternates between its frame buffers, so the next step() does
+    not overwrite the frame just returned.  `wait()` waits for everything."""
 
     def __init__(self, gather, buffers, render_streams=None):
         assert len(buffers) >= 2
@@ -117,6 +128,7 @@ class OverlappedGather:
             assert render_streams is None or len(render_streams) == len(buffers)
             self.side = torch.cuda.Stream(device=buffers[0].device)
             self.done = [None] * len(buffers)
+        self.frame_done = None
 
     def step(self, render):
         """render(buffer, slot) enqueues the render of the next frame into `buffer` on the current
@@ -142,6 +154,7 @@ class OverlappedGather:
             frame = self.gather(buf)
             self.done[b] = torch.cuda.Event()
             self.done[b].record(self.side)
+            self.frame_done = self.done[b]
         return frame
 
     def wait(self):

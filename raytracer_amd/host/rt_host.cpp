@@ -16,6 +16,7 @@
 #include <fstream>
 #include <limits>
 #include <map>
+#include <stdexcept>
 #include <memory>
 #include <string>
 #include <vector>
@@ -483,10 +484,27 @@ struct World {
     std::vector<std::shared_ptr<Shape>> objects;
     std::vector<Light> lights;
     rt_scene* scene = nullptr;  // device copy, created on first render
+    int device = -1;            // the GPU `scene` lives on
+    bool exported = false;      // rth_world_scene handed `scene` out as a raw handle
+    // Scenes whose raw handle a caller may still hold: they stay valid (describing the world as it
+    // was) until the world goes away, instead of dangling when the world changes or moves to
+    // another GPU.
+    std::vector<rt_scene*> retired;
     Flat flat;
     bool flattened = false;
+    void drop_scene() {
+        if (!scene) return;
+        if (exported)
+            retired.push_back(scene);
+        else
+            rt_scene_destroy(scene);
+        scene = nullptr;
+        exported = false;
+        device = -1;
+    }
     ~World() {
         if (scene) rt_scene_destroy(scene);
+        for (rt_scene* r : retired) rt_scene_destroy(r);
     }
 };
 struct Camera {  // scene/camera.rs:17-43
@@ -775,10 +793,24 @@ void put_box(const BoundingBox& b, double* o) {
 void put4(Tuple t, double* o) {
     o[0] = t.x; o[1] = t.y; o[2] = t.z; o[3] = t.w;
 }
-void invalidate_worlds() {
+bool contains_shape(const Shape* root, const Shape* target) {
+    if (root == target) return true;
+    for (auto& c : root->children)
+        if (contains_shape(c.get(), target)) return true;
+    return false;
+}
+// A shape changed (children added, divided, wrapped in a CSG shape): the worlds that hold it must be
+// flattened and uploaded again; the others keep their device copies.
+void invalidate_worlds_with(const Shape* changed) {
     for (auto& w : g_reg.worlds) {
-        if (w->scene) rt_scene_destroy(w->scene);
-        w->scene = nullptr;
+        bool holds = false;
+        for (auto& o : w->objects)
+            if (contains_shape(o.get(), changed)) {
+                holds = true;
+                break;
+            }
+        if (!holds) continue;
+        w->drop_scene();
         w->flattened = false;
     }
 }
@@ -788,48 +820,48 @@ void invalidate_worlds() {
 extern "C" {
 
 const char* rth_last_error(void) { return g_error.empty() ? rt_last_error() : g_error.c_str(); }
-void rth_reset(void) {
+void rth_reset(void) { try {
     g_reg = Registry();
     g_ppm.clear();
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
 
 // ---- matrices ----
-void rth_mat_identity(double* o) { Matrix::identity().store(o); }
-void rth_mat_translation(double x, double y, double z, double* o) { translation(x, y, z).store(o); }
-void rth_mat_scaling(double x, double y, double z, double* o) { scaling(x, y, z).store(o); }
-void rth_mat_rotation_x(double a, double* o) { rotation(0, a).store(o); }
-void rth_mat_rotation_y(double a, double* o) { rotation(1, a).store(o); }
-void rth_mat_rotation_z(double a, double* o) { rotation(2, a).store(o); }
-void rth_mat_shearing(double a, double b, double c, double d, double e, double f, double* o) {
+void rth_mat_identity(double* o) { try { Matrix::identity().store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_translation(double x, double y, double z, double* o) { try { translation(x, y, z).store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_scaling(double x, double y, double z, double* o) { try { scaling(x, y, z).store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_rotation_x(double a, double* o) { try { rotation(0, a).store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_rotation_y(double a, double* o) { try { rotation(1, a).store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_rotation_z(double a, double* o) { try { rotation(2, a).store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_shearing(double a, double b, double c, double d, double e, double f, double* o) { try {
     shearing(a, b, c, d, e, f).store(o);
-}
-void rth_mat_view_transform(const double* from, const double* to, const double* up, double* o) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_view_transform(const double* from, const double* to, const double* up, double* o) { try {
     view_transform(point(from[0], from[1], from[2]), point(to[0], to[1], to[2]), vec(up[0], up[1], up[2])).store(o);
-}
-void rth_mat_mul(const double* a, const double* b, double* o) { multiply(Matrix::rows(a), Matrix::rows(b)).store(o); }
-int rth_mat_inverse(const double* a, double* o) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_mul(const double* a, const double* b, double* o) { try { multiply(Matrix::rows(a), Matrix::rows(b)).store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+int rth_mat_inverse(const double* a, double* o) { try {
     Matrix r;
     if (!inverse(Matrix::rows(a), r)) return -1;
     r.store(o);
     return 0;
-}
-void rth_mat_transpose(const double* a, double* o) { transposed(Matrix::rows(a)).store(o); }
-void rth_mat_mul_tuple(const double* a, const double* t, double* o) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+void rth_mat_transpose(const double* a, double* o) { try { transposed(Matrix::rows(a)).store(o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_mat_mul_tuple(const double* a, const double* t, double* o) { try {
     put4(multiply(Matrix::rows(a), Tuple{t[0], t[1], t[2], t[3]}), o);
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
 
 // ---- patterns / materials ----
 static int64_t push_pattern(const std::shared_ptr<Pattern>& p) {
     g_reg.patterns.push_back(p);
     return (int64_t)g_reg.patterns.size() - 1;
 }
-int64_t rth_pattern_solid(double r, double g, double b) {
+int64_t rth_pattern_solid(double r, double g, double b) { try {
     auto p = std::make_shared<Pattern>();
     p->kind = RT_PAT_SOLID;
     p->color[0] = r; p->color[1] = g; p->color[2] = b;
     return push_pattern(p);
-}
-int64_t rth_pattern_binary(int kind, int64_t a, int64_t b, const double* m) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_pattern_binary(int kind, int64_t a, int64_t b, const double* m) { try {
     if (kind < RT_PAT_STRIPED || kind > RT_PAT_BLENDED) return -1;
     auto p = std::make_shared<Pattern>();
     p->kind = kind;
@@ -837,23 +869,23 @@ int64_t rth_pattern_binary(int kind, int64_t a, int64_t b, const double* m) {
     p->b = g_reg.patterns.at(b);
     p->transform = Matrix::rows(m);
     return push_pattern(p);
-}
-int64_t rth_pattern_perturbed(int64_t delegate, double scale, const double* m) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_pattern_perturbed(int64_t delegate, double scale, const double* m) { try {
     auto p = std::make_shared<Pattern>();
     p->kind = RT_PAT_PERTURBED;
     p->a = g_reg.patterns.at(delegate);
     p->scale = scale;
     p->transform = Matrix::rows(m);
     return push_pattern(p);
-}
-int64_t rth_pattern_test(const double* m) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_pattern_test(const double* m) { try {
     auto p = std::make_shared<Pattern>();
     p->kind = RT_PAT_TEST;
     p->transform = Matrix::rows(m);
     return push_pattern(p);
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 int64_t rth_phong(int64_t pattern, double ambient, double diffuse, double specular, double shininess,
-                  double reflective, double transparency, double refractive_index) {
+                  double reflective, double transparency, double refractive_index) { try {
     auto m = std::make_shared<Phong>();
     m->pattern = g_reg.patterns.at(pattern);
     m->ambient = ambient;
@@ -865,11 +897,11 @@ int64_t rth_phong(int64_t pattern, double ambient, double diffuse, double specul
     m->refractive_index = refractive_index;
     g_reg.materials.push_back(m);
     return (int64_t)g_reg.materials.size() - 1;
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 
 // ---- shapes ----
 int64_t rth_shape(int kind, const double* m, int64_t material, int casts_shadow, double minimum, double maximum,
-                  int closed) {
+                  int closed) { try {
     if (kind < RT_SPHERE || kind > RT_CONE) return -1;
     auto s = std::make_shared<Shape>();
     s->kind = kind;
@@ -880,20 +912,20 @@ int64_t rth_shape(int kind, const double* m, int64_t material, int casts_shadow,
     s->maximum = maximum;
     s->closed = closed != 0;
     return g_reg.add(s);
-}
-int64_t rth_triangle(const double* p, const double* m, int64_t material, int casts_shadow) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_triangle(const double* p, const double* m, int64_t material, int casts_shadow) { try {
     return g_reg.add(make_triangle(p, nullptr, Matrix::rows(m), g_reg.materials.at(material), casts_shadow != 0));
-}
-int64_t rth_smooth_triangle(const double* p, const double* n, const double* m, int64_t material, int casts_shadow) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_smooth_triangle(const double* p, const double* n, const double* m, int64_t material, int casts_shadow) { try {
     return g_reg.add(make_triangle(p, n, Matrix::rows(m), g_reg.materials.at(material), casts_shadow != 0));
-}
-int64_t rth_group(const double* m) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_group(const double* m) { try {
     auto s = std::make_shared<Shape>();
     s->transform = Matrix::rows(m);
     return g_reg.add(s);
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 // CSG::new (csg.rs:34-59): casts_shadow is false, both operands get the new shape as parent.
-int64_t rth_csg(int op, int64_t left, int64_t right, const double* m, int64_t material) {
+int64_t rth_csg(int op, int64_t left, int64_t right, const double* m, int64_t material) { try {
     auto s = std::make_shared<Shape>();
     s->kind = RT_CSG;
     s->op = op;
@@ -902,14 +934,15 @@ int64_t rth_csg(int op, int64_t left, int64_t right, const double* m, int64_t ma
     s->casts_shadow = false;
     s->add_child(g_reg.shapes.at(left));
     s->add_child(g_reg.shapes.at(right));
-    invalidate_worlds();
+    invalidate_worlds_with(s->children[0].get());
+    invalidate_worlds_with(s->children[1].get());
     return g_reg.add(s);
-}
-int rth_csg_allowed(int op, int lhit, int inl, int inr) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_csg_allowed(int op, int lhit, int inl, int inr) { try {
     return Shape::intersection_allowed(op, lhit != 0, inl != 0, inr != 0) ? 1 : 0;
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 // CSG::filter_intersections (csg.rs:80-107) on a caller-supplied list, survivors kept in place.
-int rth_csg_filter(int64_t h, int n, double* ts, int64_t* objs) {
+int rth_csg_filter(int64_t h, int n, double* ts, int64_t* objs) { try {
     auto& csg = g_reg.shapes.at(h);
     bool inl = false, inr = false;
     int keep = 0;
@@ -926,33 +959,33 @@ int rth_csg_filter(int64_t h, int n, double* ts, int64_t* objs) {
             inr = !inr;
     }
     return keep;
-}
-int rth_group_add_child(int64_t g, int64_t c) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_group_add_child(int64_t g, int64_t c) { try {
     auto& grp = g_reg.shapes.at(g);
     if (grp->kind != RT_GROUP) return -1;
     grp->add_child(g_reg.shapes.at(c));
-    invalidate_worlds();
+    invalidate_worlds_with(grp.get());
     return 0;
-}
-int rth_shape_kind(int64_t h) { return g_reg.shapes.at(h)->kind; }
-int rth_group_num_children(int64_t g) { return (int)g_reg.shapes.at(g)->children.size(); }
-int64_t rth_group_child(int64_t g, int i) { return g_reg.add(g_reg.shapes.at(g)->children.at(i)); }
-void rth_divide(int64_t h, int threshold) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_shape_kind(int64_t h) { try { return g_reg.shapes.at(h)->kind; } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_group_num_children(int64_t g) { try { return (int)g_reg.shapes.at(g)->children.size(); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_group_child(int64_t g, int i) { try { return g_reg.add(g_reg.shapes.at(g)->children.at(i)); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+void rth_divide(int64_t h, int threshold) { try {
     g_reg.shapes.at(h)->divide((size_t)threshold);
-    invalidate_worlds();
-}
-void rth_bounds(int64_t h, double* o) { put_box(g_reg.shapes.at(h)->bounds(), o); }
-void rth_parent_space_bounds(int64_t h, double* o) { put_box(g_reg.shapes.at(h)->parent_space_bounds_of(), o); }
-void rth_triangle_data(int64_t h, double* o) {
+    invalidate_worlds_with(g_reg.shapes.at(h).get());
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_bounds(int64_t h, double* o) { try { put_box(g_reg.shapes.at(h)->bounds(), o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_parent_space_bounds(int64_t h, double* o) { try { put_box(g_reg.shapes.at(h)->parent_space_bounds_of(), o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_triangle_data(int64_t h, double* o) { try {
     auto& s = g_reg.shapes.at(h);
     Tuple v[9] = {s->p1, s->p2, s->p3, s->e1, s->e2, s->normal, s->n1, s->n2, s->n3};
     for (int i = 0; i < 9; ++i) {
         o[i * 3] = v[i].x; o[i * 3 + 1] = v[i].y; o[i * 3 + 2] = v[i].z;
     }
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
 
 // ---- OBJ ----
-int64_t rth_obj_parse(const char* path, const double* m, int64_t material, int casts_shadow) {
+int64_t rth_obj_parse(const char* path, const double* m, int64_t material, int casts_shadow) { try {
     auto p = std::make_shared<ObjFileParser>();
     p->transform = Matrix::rows(m);
     p->material = g_reg.materials.at(material);
@@ -963,54 +996,56 @@ int64_t rth_obj_parse(const char* path, const double* m, int64_t material, int c
     }
     g_reg.parsers.push_back(p);
     return (int64_t)g_reg.parsers.size() - 1;
-}
-int rth_obj_num_vertices(int64_t h) { return (int)g_reg.parsers.at(h)->vertices.size(); }
-int rth_obj_num_normals(int64_t h) { return (int)g_reg.parsers.at(h)->vertex_normals.size(); }
-void rth_obj_vertex(int64_t h, int i, double* o) { put4(g_reg.parsers.at(h)->vertices.at(i), o); }
-void rth_obj_normal(int64_t h, int i, double* o) { put4(g_reg.parsers.at(h)->vertex_normals.at(i), o); }
-int rth_obj_num_groups(int64_t h) { return (int)g_reg.parsers.at(h)->order.size(); }
-int64_t rth_obj_group(int64_t h, const char* name) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_obj_num_vertices(int64_t h) { try { return (int)g_reg.parsers.at(h)->vertices.size(); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_obj_num_normals(int64_t h) { try { return (int)g_reg.parsers.at(h)->vertex_normals.size(); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+void rth_obj_vertex(int64_t h, int i, double* o) { try { put4(g_reg.parsers.at(h)->vertices.at(i), o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_obj_normal(int64_t h, int i, double* o) { try { put4(g_reg.parsers.at(h)->vertex_normals.at(i), o); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+int rth_obj_num_groups(int64_t h) { try { return (int)g_reg.parsers.at(h)->order.size(); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_obj_group(int64_t h, const char* name) { try {
     auto& p = g_reg.parsers.at(h);
     auto it = p->groups.find(name ? std::string(name) : p->current_group);
     if (it == p->groups.end()) return -1;
     return g_reg.add(it->second);
-}
-int64_t rth_obj_to_group(int64_t h, const double* m) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_obj_to_group(int64_t h, const double* m) { try {
     return g_reg.add(g_reg.parsers.at(h)->obj_to_group(Matrix::rows(m)));
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 
 // ---- world / camera ----
-int64_t rth_world(void) {
+int64_t rth_world(void) { try {
     g_reg.worlds.push_back(std::make_shared<World>());
     return (int64_t)g_reg.worlds.size() - 1;
-}
-void rth_world_add_object(int64_t w, int64_t s) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+void rth_world_add_object(int64_t w, int64_t s) { try {
     auto& world = g_reg.worlds.at(w);
     world->objects.push_back(g_reg.shapes.at(s));
+    world->drop_scene();
     world->flattened = false;
-}
-void rth_world_add_light(int64_t w, const double* pos, const double* col) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+void rth_world_add_light(int64_t w, const double* pos, const double* col) { try {
     Light l;
     std::memcpy(l.position, pos, sizeof l.position);
     std::memcpy(l.intensity, col, sizeof l.intensity);
     auto& world = g_reg.worlds.at(w);
     world->lights.push_back(l);
+    world->drop_scene();
     world->flattened = false;
-}
-int64_t rth_camera(int64_t hsize, int64_t vsize, double fov, const double* m) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+int64_t rth_camera(int64_t hsize, int64_t vsize, double fov, const double* m) { try {
     g_reg.cameras.push_back(std::make_shared<Camera>((size_t)hsize, (size_t)vsize, fov, Matrix::rows(m)));
     return (int64_t)g_reg.cameras.size() - 1;
-}
-void rth_camera_info(int64_t c, double* o) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+void rth_camera_info(int64_t c, double* o) { try {
     auto& cam = g_reg.cameras.at(c);
     o[0] = cam->half_width; o[1] = cam->half_height; o[2] = cam->pixel_size;
     o[3] = (double)cam->width(); o[4] = (double)cam->height();
-}
-int rth_camera_block(int64_t c, rt_camera* out) { return camera_block(*g_reg.cameras.at(c), *out) ? 0 : RT_ERR_INVALID; }
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
+int rth_camera_block(int64_t c, rt_camera* out) { try { return camera_block(*g_reg.cameras.at(c), *out) ? 0 : RT_ERR_INVALID; } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 
 // ---- flatten (inspection) ----
 // counts: nodes, xforms, aabbs, ranges, tris, materials, patterns, pattern_xforms, lights
-int rth_flatten(int64_t w, int32_t* counts) {
+int rth_flatten(int64_t w, int32_t* counts) { try {
     g_error.clear();
     auto& world = g_reg.worlds.at(w);
     if (!flatten(*world)) return RT_ERR_INVALID;
@@ -1019,103 +1054,107 @@ int rth_flatten(int64_t w, int32_t* counts) {
                     d.n_pattern_xforms, d.n_lights};
     if (counts) std::memcpy(counts, c, sizeof c);
     return 0;
-}
-int rth_flat_nodes(int64_t w, rt_node* out) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_flat_nodes(int64_t w, rt_node* out) { try {
     auto& world = g_reg.worlds.at(w);
     if (!flatten(*world)) return RT_ERR_INVALID;
     std::memcpy(out, world->flat.nodes.data(), world->flat.nodes.size() * sizeof(rt_node));
     return 0;
-}
-int rth_flat_aabbs(int64_t w, rt_aabb* out) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_flat_aabbs(int64_t w, rt_aabb* out) { try {
     auto& world = g_reg.worlds.at(w);
     if (!flatten(*world)) return RT_ERR_INVALID;
     std::memcpy(out, world->flat.aabbs.data(), world->flat.aabbs.size() * sizeof(rt_aabb));
     return 0;
-}
-int rth_flat_xforms(int64_t w, rt_xform* out) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_flat_xforms(int64_t w, rt_xform* out) { try {
     auto& world = g_reg.worlds.at(w);
     if (!flatten(*world)) return RT_ERR_INVALID;
     std::memcpy(out, world->flat.xforms.data(), world->flat.xforms.size() * sizeof(rt_xform));
     return 0;
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 // The scene description itself (pointers stay valid until the world changes).
-int rth_scene_desc(int64_t w, rt_scene_desc* out) {
+int rth_scene_desc(int64_t w, rt_scene_desc* out) { try {
     auto& world = g_reg.worlds.at(w);
     if (!flatten(*world)) return RT_ERR_INVALID;
     *out = describe(world->flat);
     return 0;
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 
 // ---- render: the replacement of src/lib.rs:77-133 ----
 static int ensure_scene(World& world, int device) {
     g_error.clear();
-    if (world.scene && world.flattened) return RT_OK;
-    if (world.scene) {
-        rt_scene_destroy(world.scene);
-        world.scene = nullptr;
-    }
+    if (world.scene && world.flattened && world.device == device) return RT_OK;
+    world.drop_scene();  // the world changed, or it is wanted on another GPU
     if (!flatten(world)) return RT_ERR_INVALID;
     rt_scene_desc d = describe(world.flat);
-    return rt_scene_create(&d, device, &world.scene);
-}
-// Uploads the world to `device` (idempotent) and returns the scene handle for direct ABI use.
-int rth_world_scene(int64_t w, int device, rt_scene** out) {
-    auto& world = g_reg.worlds.at(w);
-    int rc = ensure_scene(*world, device);
-    if (rc == RT_OK && out) *out = world->scene;
+    int rc = rt_scene_create(&d, device, &world.scene);
+    if (rc == RT_OK) world.device = device;
     return rc;
 }
-int rth_render(int64_t w, int64_t c, int device, const rt_params* params, double* rgb_out, rt_stats* stats) {
+// Uploads the world to `device` (idempotent) and returns the scene handle for direct ABI use.  The
+// handle describes the world as it is now and stays valid until rth_reset (or the end of the
+// process), also when the world is changed or rendered on another GPU afterwards.
+int rth_world_scene(int64_t w, int device, rt_scene** out) { try {
+    auto& world = g_reg.worlds.at(w);
+    int rc = ensure_scene(*world, device);
+    if (rc == RT_OK && out) {
+        *out = world->scene;
+        world->exported = true;
+    }
+    return rc;
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_render(int64_t w, int64_t c, int device, const rt_params* params, double* rgb_out, rt_stats* stats) { try {
     auto& world = g_reg.worlds.at(w);
     int rc = ensure_scene(*world, device);
     if (rc != RT_OK) return rc;
     rt_camera cam;
     if (!camera_block(*g_reg.cameras.at(c), cam)) return RT_ERR_INVALID;
     return rt_render(world->scene, &cam, params, rgb_out, stats);
-}
-int rth_render_device(int64_t w, int64_t c, int device, const rt_params* params, double* d_rgb, void* stream) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_render_device(int64_t w, int64_t c, int device, const rt_params* params, double* d_rgb, void* stream) { try {
     auto& world = g_reg.worlds.at(w);
     int rc = ensure_scene(*world, device);
     if (rc != RT_OK) return rc;
     rt_camera cam;
     if (!camera_block(*g_reg.cameras.at(c), cam)) return RT_ERR_INVALID;
     return rt_render_device(world->scene, &cam, params, d_rgb, stream);
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 // The same with Canvas::clamp applied on the device: 3 bytes per pixel (canvas.rs:50-60).
-int rth_render_u8(int64_t w, int64_t c, int device, const rt_params* params, uint8_t* rgb8_out, rt_stats* stats) {
+int rth_render_u8(int64_t w, int64_t c, int device, const rt_params* params, uint8_t* rgb8_out, rt_stats* stats) { try {
     auto& world = g_reg.worlds.at(w);
     int rc = ensure_scene(*world, device);
     if (rc != RT_OK) return rc;
     rt_camera cam;
     if (!camera_block(*g_reg.cameras.at(c), cam)) return RT_ERR_INVALID;
     return rt_render_u8(world->scene, &cam, params, rgb8_out, stats);
-}
-int rth_render_device_u8(int64_t w, int64_t c, int device, const rt_params* params, uint8_t* d_rgb8, void* stream) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int rth_render_device_u8(int64_t w, int64_t c, int device, const rt_params* params, uint8_t* d_rgb8, void* stream) { try {
     auto& world = g_reg.worlds.at(w);
     int rc = ensure_scene(*world, device);
     if (rc != RT_OK) return rc;
     rt_camera cam;
     if (!camera_block(*g_reg.cameras.at(c), cam)) return RT_ERR_INVALID;
     return rt_render_device_u8(world->scene, &cam, params, d_rgb8, stream);
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 int rth_color_at(int64_t w, int device, int64_t n, const double* origins, const double* directions, int remaining,
-                 double* rgb_out, rt_stats* stats) {
+                 double* rgb_out, rt_stats* stats) { try {
     auto& world = g_reg.worlds.at(w);
     int rc = ensure_scene(*world, device);
     if (rc != RT_OK) return rc;
     return rt_color_at(world->scene, n, origins, directions, remaining, rgb_out, stats);
-}
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
 
 // ---- canvas ----
-int rth_clamp_u8(double v) { return clamp(v); }
-int64_t rth_to_ppm(const double* rgb, int64_t w, int64_t h) {
+int rth_clamp_u8(double v) { try { return clamp(v); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_to_ppm(const double* rgb, int64_t w, int64_t h) { try {
     g_ppm = to_ppm(rgb, (size_t)w, (size_t)h);
     return (int64_t)g_ppm.size();
-}
-int64_t rth_to_ppm_u8(const uint8_t* rgb8, int64_t w, int64_t h) {
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+int64_t rth_to_ppm_u8(const uint8_t* rgb8, int64_t w, int64_t h) { try {
     g_ppm = to_ppm_u8(rgb8, (size_t)w, (size_t)h);
     return (int64_t)g_ppm.size();
-}
-void rth_ppm_copy(char* dst) { std::memcpy(dst, g_ppm.data(), g_ppm.size()); }
+} catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); return -1; } }
+void rth_ppm_copy(char* dst) { try { std::memcpy(dst, g_ppm.data(), g_ppm.size()); } catch (const std::exception& e) { g_error = std::string("invalid handle or argument: ") + e.what(); } }
 
 }  // extern "C"

@@ -250,6 +250,29 @@ def field_camera(api, width, height):
                                        api.vector(0.0, 1.0, 0.0)))
 
 
+def loose_triangles_world(api, n_grouped=20000, n_loose=300, seed=41):
+    """Small triangles in random order: n_grouped as direct children of one undivided group and
+    n_loose more directly in the world.  The reference tests each of them against every ray; for
+    the device library this is the scene whose traversal records take longest to lay out (long runs of
+    siblings to cut and sort).  Build-defined; its oracle is the CPU restatement."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    n = n_grouped + n_loose
+    centres = rng.uniform(-4, 4, (n, 3))
+    offs = rng.uniform(-0.15, 0.15, (n, 3, 3))
+    mat = api.Phong(api.Solid(api.Color(0.7, 0.5, 0.3)), 0.2, 0.7, 0.2, 50.0, 0.1, 0.0, 1.0)
+    g = api.Group()
+    loose = []
+    for k in range(n):
+        pts = [api.point(*(centres[k] + offs[k, j])) for j in range(3)]
+        t = api.Triangle(*pts, None, mat, True)
+        if k < n_grouped:
+            g.add_child(t)
+        else:
+            loose.append(t)
+    return api.World([g] + loose, [api.PointLight(api.point(-10, 10, -10), api.Color.white())])
+
+
 WORKLOADS = {
     "field": (field_world, field_camera),
     "default": (build_world, default_camera),

@@ -29,7 +29,74 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert sorted(abi.SYMBOLS) == names
 
 
+def test_constants_match_the_header():
+    """abi.py restates the limits and flag values of include/rt_abi.h; they must agree."""
+    text = open(os.path.join(ROOT, "include", "rt_abi.h")).read()
+    defines = {m.group(1): eval(m.group(2)) for m in re.finditer(r"#define (RT_[A-Z_]+) (\(?[0-9 <]+\)?)", text)}
+    assert len(defines) >= 8
+    for name, value in defines.items():
+        assert getattr(abi, name) == value, name
+    flags = re.search(r"enum \{ RT_NODE_CASTS_SHADOW.*?\};", text, flags=re.S).group(0)
+    flags = re.sub(r"/\*.*?\*/", "", flags, flags=re.S)
+    for m in re.finditer(r"(RT_NODE_[A-Z_]+) = ([0-9 <]+)", flags):
+        assert getattr(abi, m.group(1)) == eval(m.group(2)), m.group(1)
+    status = re.search(r"typedef enum rt_status \{(.*?)\}", text, flags=re.S).group(1)
+    status = re.sub(r"/\*.*?\*/", "", status, flags=re.S)
+    for m in re.finditer(r"(RT_[A-Z_]+)(?: = (-?\d+))?", status):
+        if m.group(2) is not None:
+            assert getattr(abi, m.group(1)) == int(m.group(2)), m.group(1)
+    assert abi.RT_ERR_NO_DEVICE == -4
+
+
+def test_bad_handles_are_errors_not_crashes(host):
+    """The builder interface never lets an exception cross the C boundary: an unknown handle gives an
+    error value and a message."""
+    lib = host.lib
+    ident = (C.c_double * 16)(*[1.0 if i % 5 == 0 else 0.0 for i in range(16)])
+    assert lib.rth_shape(1, ident, 12345678, 1, 0.0, 0.0, 0) == -1
+    assert b"invalid handle" in lib.rth_last_error()
+    assert lib.rth_group_add_child(99999, 99998) == -1
+    assert lib.rth_pattern_binary(1, 777777, 777778, ident) == -1
+    assert lib.rth_shape_kind(424242) == -1
+
+
+def test_a_node_must_name_its_nearest_container_as_parent(host):
+    M = host.Matrix
+    outer, inner = host.Group(), host.Group()
+    inner.add_child(host.Sphere(M.identity(), host.Phong.default(), True))
+    outer.add_child(inner)
+    world = host.World([outer], [])
+    desc = host.scene_desc(world)
+    nodes = (abi.rt_node * desc.n_nodes)(*[desc.nodes[i] for i in range(desc.n_nodes)])
+    broken = abi.rt_scene_desc.from_buffer_copy(desc)
+    broken.nodes = nodes
+    handle = C.c_void_p()
+    assert [n.parent for n in nodes] == [-1, 0, 1]
+    nodes[2].parent = 0   # the grandparent: an earlier container whose subtree covers the node, but not the nearest
+    assert host.abi.rt_scene_create(C.byref(broken), 0, C.byref(handle)) == abi.RT_ERR_INVALID
+    assert b"nearest enclosing" in host.abi.rt_last_error()
+
+
+def test_multi_create_validates_before_it_needs_a_gpu(host):
+    lib = host.abi
+    world = scenes.build_world(host)
+    desc = host.scene_desc(world)
+    handle = C.c_void_p()
+    assert lib.rt_multi_create(C.byref(desc), 0, None, C.byref(handle)) == abi.RT_ERR_INVALID
+    assert lib.rt_multi_create(C.byref(desc), 65, None, C.byref(handle)) == abi.RT_ERR_INVALID
+    rc = lib.rt_multi_create(C.byref(desc), 1, None, C.byref(handle))
+    if lib.rt_device_count() == 0:
+        assert rc == abi.RT_ERR_NO_DEVICE and not handle
+        broken = abi.rt_scene_desc.from_buffer_copy(desc)
+        broken.n_lights = 5
+        assert lib.rt_multi_create(C.byref(broken), 1, None, C.byref(handle)) == abi.RT_ERR_LIMIT
+    else:
+        assert rc == abi.RT_OK
+        lib.rt_multi_destroy(handle)
+
+
 def test_struct_sizes():
+    assert C.sizeof(abi.rt_multi_stats) == 48
     assert C.sizeof(abi.rt_node) == 32
     assert C.sizeof(abi.rt_xform) == 192
     assert C.sizeof(abi.rt_aabb) == 48

@@ -103,3 +103,28 @@ def test_overlapped_byte_gather(tmp_path, world_size, size, mode):
     yy, xx, cc = np.meshgrid(np.arange(H), np.arange(W), np.arange(3), indexing="ij")
     for k in range(3):
         assert np.array_equal(frames[k], ((yy * 7 + xx * 3 + cc * 11 + k * 5) % 256).astype(np.uint8))
+
+
+@pytest.mark.parametrize("world_size", [2, 3])
+def test_spawned_ranks_assemble_a_frame(world_size):
+    """bench.py --gpus N without a launcher starts its own ranks with raytracer_amd.launch.spawn_ranks:
+    fresh interpreters that find RANK / WORLD_SIZE / MASTER_* in their environment.  Here the ranks
+    are CPU processes on gloo."""
+    import hashlib
+    import json
+    from raytracer_amd.launch import spawn_ranks
+    W, H = 20, 45
+    status, out = spawn_ranks([os.path.join(ROOT, "tests", "rank_worker.py"), str(W), str(H)], world_size, timeout=240)
+    assert status == 0
+    lines = [l for l in out.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    got = json.loads(lines[0])
+    yy, xx, cc = np.meshgrid(np.arange(H), np.arange(W), np.arange(3), indexing="ij")
+    want = ((yy * 7 + xx * 3 + cc * 11) % 256).astype(np.uint8)
+    assert got == {"n": world_size, "sha": hashlib.sha256(want.tobytes()).hexdigest()}
+
+
+def test_spawned_ranks_report_a_failing_rank():
+    from raytracer_amd.launch import spawn_ranks
+    status, out = spawn_ranks([os.path.join(ROOT, "tests", "rank_worker.py"), "8", "8", "1"], 2, timeout=120)
+    assert status != 0

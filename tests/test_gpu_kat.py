@@ -232,6 +232,37 @@ def quadric_world(api, seed):
     return api.World(objects, lights)
 
 
+def sheared_world(api, seed):
+    """Quadrics under strongly sheared transforms and under a stretch applied AFTER a rotation: maps
+    whose smallest stretch is far below the length of any column of the matrix, which is what the
+    padding of the cull boxes has to be sized by."""
+    rng = np.random.default_rng(7000 + seed)
+    M = api.Matrix
+    objects = []
+    while len(objects) < 10:
+        rot = M.rotation_y(rng.uniform(-3, 3)) * M.rotation_z(rng.uniform(-3, 3))
+        if rng.random() < 0.5:
+            t = M.scaling(*(10.0 ** rng.uniform(-1.0, 0.7, 3))) * rot          # stretch after rotation
+        else:
+            t = rot * M.shearing(*rng.uniform(-3.0, 3.0, 6)) * M.scaling(*(10.0 ** rng.uniform(-0.7, 0.3, 3)))
+        t = M.translation(*rng.uniform(-4, 4, 3)) * t
+        try:
+            t.inverse()
+        except ValueError:
+            continue  # |det| < 1e-5: the reference would panic on it
+        m = api.Phong(api.Solid(api.Color(*rng.uniform(0, 1, 3))), 0.2, 0.7, 0.3, 50.0,
+                      float(rng.choice([0.0, 0.4])), float(rng.choice([0.0, 0.0, 0.8])), float(rng.uniform(1.0, 2.0)))
+        k = len(objects) % 3
+        if k == 0:
+            objects.append(api.Sphere(t, m, True))
+        elif k == 1:
+            objects.append(api.Cube(t, m, True))
+        else:
+            objects.append(api.Cylinder(t, m, True, -1.0, 1.5, True))
+    lights = [api.PointLight(api.point(*rng.uniform(-12, 12, 3)), api.Color.white()) for _ in range(2)]
+    return api.World(objects, lights)
+
+
 def triangle_fan_group(api, rng):
     """A small closed mesh (an octahedron subdivided once: 32 triangles) in a transformed group,
     divided like the OBJ meshes are, so that sibling runs get cluster boxes and groups get pruned."""
@@ -311,14 +342,14 @@ def mixed_world(api, seed):
     return api.World(objects, base.lights)
 
 
-@pytest.mark.parametrize("kind", ["flat", "grouped", "mixed"])
+@pytest.mark.parametrize("kind", ["flat", "grouped", "mixed", "sheared"])
 @pytest.mark.parametrize("seed", list(range(8)))
 def test_culling_is_conservative(host, orc, seed, kind):
     """Rays from 10 to 10^7 units away aimed at and just past the silhouettes of the objects: the
     padded boxes (single leaves, runs of siblings) and the pruning of groups by their box times
     must keep every ray the exact arithmetic counts as a hit, including the false hits that
     cancellation produces for far origins."""
-    make = {"flat": quadric_world, "grouped": grouped_world, "mixed": mixed_world}[kind]
+    make = {"flat": quadric_world, "grouped": grouped_world, "mixed": mixed_world, "sheared": sheared_world}[kind]
     rng = np.random.default_rng(seed)
     origins, dirs = [], []
     for dist in (10.0, 1e3, 1e5, 1e7):

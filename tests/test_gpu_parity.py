@@ -67,21 +67,7 @@ def test_many_loose_triangles(host, orc):
     cut of very long runs).  The reference tests each of them against every ray."""
     import time
     rng = np.random.default_rng(41)
-    centres = rng.uniform(-4, 4, (20300, 3))
-    offs = rng.uniform(-0.15, 0.15, (20300, 3, 3))
-
-    def world(api):
-        mat = api.Phong(api.Solid(api.Color(0.7, 0.5, 0.3)), 0.2, 0.7, 0.2, 50.0, 0.1, 0.0, 1.0)
-        g = api.Group()
-        loose = []
-        for k in range(20300):
-            pts = [api.point(*(centres[k] + offs[k, j])) for j in range(3)]
-            t = api.Triangle(*pts, None, mat, True)
-            if k < 20000:
-                g.add_child(t)
-            else:
-                loose.append(t)
-        return api.World([g] + loose, [api.PointLight(api.point(-10, 10, -10), api.Color.white())])
+    world = scenes.loose_triangles_world
     n = 1200
     o = np.tile(np.array([0.0, 1.0, -12.0]), (n, 1))
     d = np.array([0.0, -0.08, 1.0]) + rng.uniform(-0.3, 0.3, (n, 3))

@@ -8,5 +8,5 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export PYTHONPATH=$ROOT TMPDIR=/tmp
 cd /tmp
-timeout -s KILL 120 rocprofv3 --pmc $CNT --output-format csv -d $OUT -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $OUT.log 2>&1
+timeout -s KILL 120 rocprofv3 --pmc $CNT --output-format csv -d $OUT -o p -- python $ROOT/bench.py --steps 2 --warmup 1 --no-extras "$@" > $OUT.log 2>&1
 python $ROOT/tools/pmc_summary.py $OUT/p_counter_collection.csv

@@ -9,9 +9,9 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export PYTHONPATH=$ROOT TMPDIR=/tmp
 cd /tmp
-BENCH="python $ROOT/bench.py --steps 50 --warmup 3 --no-cpu-baseline $*"
+BENCH="python $ROOT/bench.py --steps 50 --warmup 3 --no-extras $*"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o t -- $BENCH > $OUT/trace.log 2>&1
-PMC_BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline $*"
+PMC_BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-extras $*"
 i=0
 for counters in \
   "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" \

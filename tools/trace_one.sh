@@ -7,5 +7,5 @@ OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 export PYTHONPATH=$ROOT TMPDIR=/tmp
 cd /tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOT/bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $OUT.log 2>&1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o t -- python $ROOT/bench.py --steps 20 --warmup 3 --no-extras "$@" > $OUT.log 2>&1
 cut -d, -f1-4 $OUT/t_kernel_stats.csv | sed 's/(anonymous namespace):://g' | cut -c1-150
