@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "csrc", "librt_amd.so")
+# RT_AMD_LIB: diagnostic builds of the same library (profiling counters, tuning variants)
+LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "csrc", "librt_amd.so")
 
 RT_MAX_LIGHTS = 4
 RT_MAX_DEPTH = 5

@@ -127,6 +127,8 @@ struct DevJob {
     int out_u8;       // the output is 3 bytes per pixel, quantised like Canvas::clamp, instead of 3 doubles
     const int* tile_order;  // three arrays of tiles_x * local_tile_rows tile indices, one per cost class, or null
     const unsigned long long* tile_class_count;  // how many tiles each class holds
+    int split;              // class-2 tiles (transparent hits) are rendered in `split` horizontal strips, one wavefront each: 1, 2 or 4
+    long long extra_blocks; // workgroups launched beyond one per tile, for those strips
     // ray-list mode (rt_color_at)
     long long n_rays;
     const double* ray_o;
@@ -336,6 +338,10 @@ struct Hit {
 #ifdef RT_PROFILE
     int visits;  // records visited by the wavefront (diagnostic build only)
 #endif
+#ifdef RT_PROFILE_MIX
+    // diagnostic build: records visited by kind and how many lanes took part in each
+    int n_cull, a_cull, n_group, a_group, n_leaf, a_leaf, n_leaf_idle;
+#endif
 };
 
 // Lanes of the wavefront for which the predicate holds, straight from the comparison's lane mask
@@ -380,6 +386,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     h.b_id = -1;
 #ifdef RT_PROFILE
     h.visits = 0;
+#endif
+#ifdef RT_PROFILE_MIX
+    h.n_cull = h.a_cull = h.n_group = h.a_group = h.n_leaf = h.a_leaf = h.n_leaf_idle = 0;
 #endif
     if (wave_ballot(active) == 0ull) return;
 
@@ -495,6 +504,14 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             i = i + 1;
             continue;
         }
+#ifdef RT_PROFILE_MIX
+        {
+            const int lanes = __builtin_popcountll(wave_ballot(act));
+            if (type == T_CULL) { ++h.n_cull; h.a_cull += lanes; }
+            else if (type == RT_GROUP || type == T_CSG_BEGIN) { ++h.n_group; h.a_group += lanes; }
+            else if (type < T_XFORM) { ++h.n_leaf; h.a_leaf += lanes; if (lanes == 0) ++h.n_leaf_idle; }
+        }
+#endif
         if (CULL && type == T_CULL) {
             // Box p[0..5] grown by r0 + r1 * |origin|^2: r0 covers the rounding of this test, the
             // second term the rounding of the leaf's own quadratic for far-away origins (its
@@ -864,6 +881,84 @@ DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
     return n;
 }
 
+// Shape::normal_at (shape.rs:52-59) for the point where the ray (ro, rd) hits the leaf `sr`: the point
+// to object space, the leaf's local_normal_at, and the normal back to world space.
+DI V3 normal_at(const DevScene& S, const RT_CONST SRec* sr, V3 ro, V3 rd, V3 point) {
+    const int type = sr->type;
+    const int sflags = sr->flags;
+    const int data = sr->tri;
+    V3 lp = to_object(S, sr, point);
+    V3 ln;
+    switch (type) {
+        case RT_SPHERE:  // sphere.rs:109-111
+            ln = lp;
+            break;
+        case RT_PLANE:  // plane.rs:105-107: the plane's own inverse times (0, 1, 0)
+            ln = (sflags & S_HAS_XFORM) ? mk(sr->inv[1], sr->inv[5], sr->inv[9]) : mk(0.0, 1.0, 0.0);
+            break;
+        case RT_CUBE: {  // cube.rs:129-142
+            double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+            double maxc = fmax(fmax(ax, ay), az);
+            if (maxc == ax)
+                ln = mk(lp.x, 0.0, 0.0);
+            else if (maxc == ay)
+                ln = mk(0.0, lp.y, 0.0);
+            else
+                ln = mk(0.0, 0.0, lp.z);
+            break;
+        }
+        case RT_CYLINDER:
+        case RT_CONE: {  // cylinder.rs:184-197, cone.rs:194-213
+            double mn = sr->r0, mx = sr->r1;
+            double dist = lp.x * lp.x + lp.z * lp.z;
+            if (dist < 1.0 && lp.y >= mx - RT_EPS) {
+                ln = mk(0.0, 1.0, 0.0);
+            } else if (dist < 1.0 && lp.y <= mn + RT_EPS) {
+                ln = mk(0.0, -1.0, 0.0);
+            } else if (type == RT_CYLINDER) {
+                ln = mk(lp.x, 0.0, lp.z);
+            } else {
+                double y = sqrt(dist);
+                ln = mk(lp.x, lp.y > 0.0 ? -y : y, lp.z);
+            }
+            break;
+        }
+        case RT_TRIANGLE:  // triangle.rs:142-144
+            ln = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
+            break;
+        default: {  // smooth_triangle.rs:160-162
+            // The hit's u and v (smooth_triangle.rs:101-129) are not carried through the
+            // traversal: the same operations on the same ray give the same bits here.
+            V3 lo = ro, ld = rd;
+#pragma unroll
+            for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
+                if (sr->anc_xf[k] >= 0) {
+                    const RT_CONST double* m = S.xforms[sr->anc_xf[k]].inv;
+                    lo = xpoint(m, lo);
+                    ld = xvec(m, ld);
+                }
+            if (sflags & S_HAS_XFORM) {
+                lo = xpoint(sr->inv, lo);
+                ld = xvec(sr->inv, ld);
+            }
+            V3 tp1 = mk(S.tris[data].p1[0], S.tris[data].p1[1], S.tris[data].p1[2]);
+            V3 te1 = mk(S.tris[data].e1[0], S.tris[data].e1[1], S.tris[data].e1[2]);
+            V3 te2 = mk(S.tris[data].e2[0], S.tris[data].e2[1], S.tris[data].e2[2]);
+            V3 dir_cross_e2 = cross(ld, te2);
+            double tf = 1.0 / dot(te1, dir_cross_e2);
+            V3 p1_to_origin = lo - tp1;
+            double hit_u = tf * dot(p1_to_origin, dir_cross_e2);
+            double hit_v = tf * dot(ld, cross(p1_to_origin, te1));
+            V3 a1 = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
+            V3 a2 = mk(S.trin[data].n2[0], S.trin[data].n2[1], S.trin[data].n2[2]);
+            V3 a3 = mk(S.trin[data].n3[0], S.trin[data].n3[1], S.trin[data].n3[2]);
+            ln = (a2 * hit_u) + (a3 * hit_v) + (a1 * (1.0 - hit_u - hit_v));
+            break;
+        }
+    }
+    return normal_to_world(S, sr, ln);
+}
+
 // Improved-noise permutation (Ken Perlin, 2002), as used by patterns/perturbed.rs:8-34.
 __constant__ unsigned char PERLIN_PERM[256] = {
     151, 160, 137, 91,  90,  15,  131, 13,  201, 95,  96,  53,  194, 233, 7,   225, 140, 36,  103,
@@ -1009,11 +1104,34 @@ DI unsigned clamp_u8(double c) {
 struct Frame {
     double surf[RT_MAX_LIGHTS][3];  // surface colour per light, in light order
     double refl[3];                 // reflected colour * reflective (written once it is known)
-    double rray[6];                 // pending refraction ray (under_point, direction); only with a refraction
+    double rray[6];                 // pending refraction ray (under_point, direction); only with a refraction.  Once the
+                                    // refraction has been handed to another lane, rray[0..2] receives its colour.
     double k;                       // Schlick reflectance; only when state bit2 is set
     int node;                       // the hit leaf: its reflective / transparency are re-read on return
-    int state;                      // bit0: waiting for refraction (else reflection); bit1: refraction still to trace; bit2: use Schlick
+    int state;                      // F_* bits
 };
+enum {
+    F_WAIT_REFR = 1,   // waiting for the refracted colour (else for the reflected one)
+    F_REFR_TODO = 2,   // there is a refraction ray that has not been traced to the end yet
+    F_SCHLICK = 4,     // combine with the Schlick factor k
+    F_HANDED = 8,      // the refraction subtree is being traced by another lane of the wavefront
+    F_ARRIVED = 16     // ... and its colour has arrived in rray[0..2]
+};
+// Work sharing inside a wavefront.  A pixel whose hits are both reflective and transparent is a
+// binary tree of up to 63 color_at calls; a lane walks it depth first, one call per round of the
+// wavefront, so such a lane keeps its wavefront alive long after the other lanes have finished.
+// Lanes without work (their pixel is done, or they never had one: see DevJob::split) therefore take
+// over refraction subtrees of busy lanes.  Per lane, packed in one word:
+//   bits 0-2   depth of the subtree's root call below the primary ray (remaining = max_depth - depth - sp)
+//   bits 3-8   lane that handed the subtree over, bits 9-11 the frame of that lane which waits for its colour
+//   bit 12     this lane traces a handed-over subtree (else its own pixel)
+//   bits 13-14 L_WAITING: the top frame waits for a handed-over subtree; L_HOLDING: a finished subtree's colour
+//              waits (in frames[0].refl) to be delivered
+//   bits 16-20 frames of this lane whose refraction ray has neither been traced nor handed over
+// A subtree's colour is computed by the same operations on the same values whichever lane does
+// it, and the combination stays with the frame, so the result is bit for bit the depth-first one.
+enum { L_DEPTH = 7, L_FROM_SHIFT = 3, L_FRAME_SHIFT = 9, L_HELPER = 1 << 12, L_WAITING = 1 << 13, L_HOLDING = 1 << 14,
+       L_TODO_SHIFT = 16 };
 
 // ((acc + surface) + reflected [* k]) + refracted [* (1 - k)] per light, world.rs:183-192.
 DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
@@ -1064,7 +1182,8 @@ DI void primary_ray(const DevJob& J, int px, int py, V3& ro, V3& rd) {
 // started among the last ones is what the whole frame then waits for).  The render kernel takes the
 // tiles class 2 first.  This only permutes the order in which tiles are rendered.
 template <bool XF, bool CULL, bool CSGM>
-__global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, long long n_tiles, int* __restrict__ tile_class) {
+__global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, long long n_tiles, int probe_bounces,
+                                                        int* __restrict__ tile_class) {
     const int lane = threadIdx.x;
     const long long tile = (long long)blockIdx.x * 64 + lane;
     const bool active = tile < n_tiles;
@@ -1081,6 +1200,30 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
     if (active && h.found) {
         const RT_CONST SRec* sr = S.shade + h.node;
         cls = sr->transp != 0.0 ? 2 : (sr->refl != 0.0 ? 1 : 0);
+    }
+    // A mirror that shows a transparent surface is as expensive as the surface itself (the pixel's
+    // tree of color_at calls forks one level further down): follow the reflection of the centre ray.
+    // Only a classification: it decides when and in how many strips a tile is rendered, not a pixel.
+    for (int bounce = 0; bounce < probe_bounces; ++bounce) {
+        const bool follow = active && cls == 1 && h.found;
+        if (wave_ballot(follow) == 0ull) break;
+        if (follow) {
+            const RT_CONST SRec* sr = S.shade + h.node;
+            const V3 point = ro + (rd * h.t);
+            V3 n = normal_at(S, sr, ro, rd, point);
+            if (dot(n, -rd) < 0.0) n = -n;
+            ro = point + (n * RT_EPS);
+            rd = reflect(rd, n);
+        }
+        trace<MODE_CLOSEST, XF, CULL, CSGM>(S, follow, ro, rd, 0.0, h);
+        if (follow) {
+            if (!h.found)
+                h.node = -1;
+            else if (S.shade[h.node].transp != 0.0)
+                cls = 2;
+            else if (S.shade[h.node].refl == 0.0)
+                h.found = false;  // the chain of mirrors ends here
+        }
     }
     if (active) tile_class[tile] = cls;
 }
@@ -1140,26 +1283,43 @@ __global__ void __launch_bounds__(ORDER_BLOCK) tile_order_kernel(int tiles_x, in
 // expensive region of the frame is spread over all of them (giving each XCD a contiguous band of
 // tiles instead puts the default scene's glass sphere on one XCD and costs 60 % more time).
 // Cheap enough to evaluate twice instead of holding the result in registers.
-DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& local_y, int& lty) {
-    const unsigned b = blockIdx.x;
-    long long tile = (long long)b * RT_BLOCK_WAVES + wave;
+// rows: how many of the tile's rows this wavefront renders (8, or 8 / split for a strip of a class-2
+// tile); lanes whose row is beyond that have no pixel.  origin: index of the strip's first pixel in
+// the rank's compact buffer (wave-uniform).
+DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& row_in_tile, int& lty, int& rows, long long& origin) {
+    const long long b = (long long)blockIdx.x * RT_BLOCK_WAVES + wave;
     const long long n_tiles = (long long)J.tiles_x * J.local_tile_rows;
-    if (J.tile_order && tile < n_tiles) {
+    long long tile = b < n_tiles ? b : n_tiles;
+    int strip = 0, split = 1;
+    rows = RT_TILE;
+    if (J.tile_order) {
         // expensive classes first: class 2, then 1, then 0
         long long n2 = (long long)J.tile_class_count[2], n1 = (long long)J.tile_class_count[1];
         n2 = n2 < n_tiles ? n2 : n_tiles;  // the three counts add up to n_tiles; clamped so that no index below can leave its array
         n1 = n1 < n_tiles - n2 ? n1 : n_tiles - n2;
-        tile = tile < n2 ? J.tile_order[2 * n_tiles + tile]
-                         : (tile < n2 + n1 ? J.tile_order[n_tiles + (tile - n2)] : J.tile_order[tile - n2 - n1]);
+        if (J.split > 1 && n2 * (J.split - 1) <= J.extra_blocks) split = J.split;  // else there are too many: whole tiles
+        const long long n2s = n2 * split;
+        if (b < n2s) {
+            strip = (int)(b % split);
+            rows = RT_TILE / split;
+            tile = J.tile_order[2 * n_tiles + b / split];
+        } else {
+            const long long t = b - n2s + n2;
+            tile = t >= n_tiles ? n_tiles : (t < n2 + n1 ? J.tile_order[n_tiles + (t - n2)] : J.tile_order[t - n2 - n1]);
+        }
         if (tile < 0 || tile >= n_tiles) tile = n_tiles;  // never trust a table for an address: renders nothing
     }
     const int tx = (int)(tile % J.tiles_x);
     lty = (int)(tile / J.tiles_x);
     px = tx * RT_TILE + (lane & 7);
-    local_y = lty * RT_TILE + (lane >> 3);
+    row_in_tile = strip * rows + (lane >> 3);
+    origin = ((long long)lty * RT_TILE + strip * rows) * J.width + (long long)tx * RT_TILE;
 }
 
-template <bool TRACK, bool XF, bool CULL, bool CSGM>
+// SHARE: lanes without work take over refraction subtrees of busy lanes (see L_*).  Used for frames
+// small enough that their time is that of their longest wavefront; on large frames the GPU is busy
+// anyway and the bookkeeping only costs.
+template <bool TRACK, bool XF, bool CULL, bool CSGM, bool SHARE = false>
 __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters,
                                                  unsigned long long* __restrict__ clear_counters) {
@@ -1184,8 +1344,11 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     my_pixel[1] = 0.0;
     my_pixel[2] = 0.0;
 
-    bool pending;
+    bool pending;  // this lane has a ray to trace in the coming round
+    bool valid;    // this lane owns a pixel (or a caller-supplied ray) and stores its colour
     V3 ro, rd;
+    int rows = RT_TILE;     // rows of the tile this wavefront renders (fewer for a strip of a class-2 tile)
+    long long origin = 0;   // first pixel of the tile or strip in the output
     if (J.n_rays > 0) {
         // World::color_at for caller-supplied rays.
         long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1194,17 +1357,18 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         ro = mk(J.ray_o[rr * 3], J.ray_o[rr * 3 + 1], J.ray_o[rr * 3 + 2]);
         rd = mk(J.ray_d[rr * 3], J.ray_d[rr * 3 + 1], J.ray_d[rr * 3 + 2]);
     } else {
-        int px, local_y, lty;
-        lane_pixel(J, wave, lane, px, local_y, lty);
-        const int py = (lty * J.world_size + J.rank) * RT_TILE + (lane >> 3);
-        pending = lty < J.local_tile_rows && px < J.width && py < J.height;
+        int px, row_in_tile, lty;
+        lane_pixel(J, wave, lane, px, row_in_tile, lty, rows, origin);
+        const int py = (lty * J.world_size + J.rank) * RT_TILE + row_in_tile;
+        pending = (lane >> 3) < rows && lty < J.local_tile_rows && px < J.width && py < J.height;
         primary_ray(J, px, py, ro, rd);
     }
-    const bool valid = pending;
+    valid = pending;
+    int job = 0;  // see L_*: a lane starts on its own pixel, or with nothing
 
     unsigned n_primary = pending ? 1u : 0u, n_shadow = 0u, n_reflect = 0u, n_refract = 0u;
     Frame frames[RT_MAX_FRAMES];
-    int sp = 0;  // suspended calls; the ray being traced has remaining = max_depth - sp
+    int sp = 0;  // suspended calls of this lane's subtree; the ray being traced has remaining = max_depth - depth - sp
     const int L = S.n_lights;
 
 #ifdef RT_PROFILE
@@ -1212,17 +1376,35 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     unsigned long long prof_closest = 0, prof_shadow = 0, prof_visits = 0, prof_traces = 0, prof_rounds = 0;
     unsigned long long prof_prepare = 0, prof_light = 0, prof_return = 0;
 #endif
-    while (wave_ballot(pending) != 0ull) {
+#ifdef RT_PROFILE_MIX
+    unsigned long long mix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RT_MIX_ADD(hh) do { mix[0] += (hh).n_cull; mix[1] += (hh).a_cull; mix[2] += (hh).n_group; mix[3] += (hh).a_group; \
+                            mix[4] += (hh).n_leaf; mix[5] += (hh).a_leaf; mix[6] += (hh).n_leaf_idle; mix[7] += 1; } while (0)
+#else
+#define RT_MIX_ADD(hh) do { } while (0)
+#endif
+#ifdef RT_PROFILE_MIX
+    unsigned long long mix_rounds = 0, mix_handoffs = 0, mix_lane_rounds = 0;
+#endif
+    while (wave_ballot(pending || (SHARE && (job & (L_WAITING | L_HOLDING)) != 0)) != 0ull) {
         Hit h;
+#ifdef RT_PROFILE_MIX
+        ++mix_rounds;
+        mix_lane_rounds += __builtin_popcountll(wave_ballot(pending));
+#endif
 #ifdef RT_PROFILE
         unsigned long long pt = __builtin_amdgcn_s_memtime();
 #endif
         trace<MODE_CLOSEST, XF, CULL, CSGM>(S, pending, ro, rd, 0.0, h);
+        RT_MIX_ADD(h);
         if (TRACK) {
             // n1/n2 (world.rs:99-132) are only read when the hit material is transparent
             // (world.rs:185, 243-246): only those lanes run the container pass.
             const bool need = pending && h.found && S.shade[h.node].transp != 0.0;
-            if (wave_ballot(need) != 0ull) trace<MODE_CONTAINERS, XF, CULL, CSGM>(S, need, ro, rd, 0.0, h);
+            if (wave_ballot(need) != 0ull) {
+                trace<MODE_CONTAINERS, XF, CULL, CSGM>(S, need, ro, rd, 0.0, h);
+                RT_MIX_ADD(h);
+            }
         }
 #ifdef RT_PROFILE
         prof_closest += __builtin_amdgcn_s_memtime() - pt;
@@ -1240,87 +1422,15 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         V3 over = mk(0.0, 0.0, 0.0), normalv = over, colour = over;
         bool want_refl = false, want_refr = false;
         if (shade) {
-            const int type = sr->type;
             const int sflags = sr->flags;
-            const int data = sr->tri;
             V3 point = ro + (rd * h.t);  // Ray::position (ray.rs:24-26)
             V3 eyev = -rd;
-            // Shape::normal_at (shape.rs:52-59)
-            V3 lp = to_object(S, sr, point);
-            V3 ln;
-            switch (type) {
-                case RT_SPHERE:  // sphere.rs:109-111
-                    ln = lp;
-                    break;
-                case RT_PLANE:  // plane.rs:105-107: the plane's own inverse times (0, 1, 0)
-                    ln = (sflags & S_HAS_XFORM) ? mk(sr->inv[1], sr->inv[5], sr->inv[9]) : mk(0.0, 1.0, 0.0);
-                    break;
-                case RT_CUBE: {  // cube.rs:129-142
-                    double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
-                    double maxc = fmax(fmax(ax, ay), az);
-                    if (maxc == ax)
-                        ln = mk(lp.x, 0.0, 0.0);
-                    else if (maxc == ay)
-                        ln = mk(0.0, lp.y, 0.0);
-                    else
-                        ln = mk(0.0, 0.0, lp.z);
-                    break;
-                }
-                case RT_CYLINDER:
-                case RT_CONE: {  // cylinder.rs:184-197, cone.rs:194-213
-                    double mn = sr->r0, mx = sr->r1;
-                    double dist = lp.x * lp.x + lp.z * lp.z;
-                    if (dist < 1.0 && lp.y >= mx - RT_EPS) {
-                        ln = mk(0.0, 1.0, 0.0);
-                    } else if (dist < 1.0 && lp.y <= mn + RT_EPS) {
-                        ln = mk(0.0, -1.0, 0.0);
-                    } else if (type == RT_CYLINDER) {
-                        ln = mk(lp.x, 0.0, lp.z);
-                    } else {
-                        double y = sqrt(dist);
-                        ln = mk(lp.x, lp.y > 0.0 ? -y : y, lp.z);
-                    }
-                    break;
-                }
-                case RT_TRIANGLE:  // triangle.rs:142-144
-                    ln = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
-                    break;
-                default: {  // smooth_triangle.rs:160-162
-                    // The hit's u and v (smooth_triangle.rs:101-129) are not carried through the
-                    // traversal: the same operations on the same ray give the same bits here.
-                    V3 lo = ro, ld = rd;
-#pragma unroll
-                    for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
-                        if (sr->anc_xf[k] >= 0) {
-                            const RT_CONST double* m = S.xforms[sr->anc_xf[k]].inv;
-                            lo = xpoint(m, lo);
-                            ld = xvec(m, ld);
-                        }
-                    if (sflags & S_HAS_XFORM) {
-                        lo = xpoint(sr->inv, lo);
-                        ld = xvec(sr->inv, ld);
-                    }
-                    V3 tp1 = mk(S.tris[data].p1[0], S.tris[data].p1[1], S.tris[data].p1[2]);
-                    V3 te1 = mk(S.tris[data].e1[0], S.tris[data].e1[1], S.tris[data].e1[2]);
-                    V3 te2 = mk(S.tris[data].e2[0], S.tris[data].e2[1], S.tris[data].e2[2]);
-                    V3 dir_cross_e2 = cross(ld, te2);
-                    double tf = 1.0 / dot(te1, dir_cross_e2);
-                    V3 p1_to_origin = lo - tp1;
-                    double hit_u = tf * dot(p1_to_origin, dir_cross_e2);
-                    double hit_v = tf * dot(ld, cross(p1_to_origin, te1));
-                    V3 a1 = mk(S.trin[data].n1[0], S.trin[data].n1[1], S.trin[data].n1[2]);
-                    V3 a2 = mk(S.trin[data].n2[0], S.trin[data].n2[1], S.trin[data].n2[2]);
-                    V3 a3 = mk(S.trin[data].n3[0], S.trin[data].n3[1], S.trin[data].n3[2]);
-                    ln = (a2 * hit_u) + (a3 * hit_v) + (a1 * (1.0 - hit_u - hit_v));
-                    break;
-                }
-            }
-            normalv = normal_to_world(S, sr, ln);
+            normalv = normal_at(S, sr, ro, rd, point);  // Shape::normal_at (shape.rs:52-59)
             if (dot(normalv, eyev) < 0.0) normalv = -normalv;
             over = point + (normalv * RT_EPS);
 
             // ---- which secondary rays this hit needs (world.rs:214-275) ----------------------
-            const int remaining = J.max_depth - sp;
+            const int remaining = J.max_depth - (SHARE ? (job & L_DEPTH) : 0) - sp;
             const double refl_c = sr->refl, transp = sr->transp;
             want_refl = remaining > 0 && !(fabs(refl_c - 0.0) < RT_EPS);
             V3 refr_dir = mk(0.0, 0.0, 0.0);
@@ -1356,7 +1466,8 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                 // plain reflections and hold the surface colours, the node and the state.
                 Frame& f = frames[sp];
                 f.node = node;
-                f.state = want_refl ? ((want_refr ? 2 : 0) | (use_k ? 4 : 0)) : (1 | (use_k ? 4 : 0));
+                f.state = (want_refl ? (want_refr ? F_REFR_TODO : 0) : F_WAIT_REFR) | (use_k ? F_SCHLICK : 0);
+                if (SHARE && want_refl && want_refr) job |= 1 << (L_TODO_SHIFT + sp);  // a subtree another lane may take
                 if (use_k) f.k = kk;
                 if (want_refr) {
                     V3 under = point - (normalv * RT_EPS);
@@ -1434,6 +1545,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
             park[11][lane] = acc.z;
             asm volatile("" ::: "memory");  // the values must really leave the registers ...
             trace<MODE_SHADOW, XF, CULL, CSGM>(S, shadow_matters, over, lightv, distance, sh);
+            RT_MIX_ADD(sh);
             asm volatile("" ::: "memory");  // ... and come back from LDS, not from a copy the compiler kept
             normalv = mk(park[0][lane], park[1][lane], park[2][lane]);
             colour = mk(park[3][lane], park[4][lane], park[5][lane]);
@@ -1487,43 +1599,67 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         unsigned long long pr0 = __builtin_amdgcn_s_memtime();
 #endif
         // ---- suspend, or return the colour up the stack ----------------------------------------
-        if (pending) {
-            V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
-            bool returning = true;
-            if (has_children) {
-                const Frame& f = frames[sp];
-                if (want_refl) {
-                    rd = reflect(rd, normalv);  // reflectv (world.rs:92)
-                    ro = over;
-                    ++n_reflect;
-                } else {
-                    ro = mk(f.rray[0], f.rray[1], f.rray[2]);
-                    rd = mk(f.rray[3], f.rray[4], f.rray[5]);
-                    ++n_refract;
-                }
-                ++sp;
-                returning = false;
+        V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
+        bool returning = pending;
+        if (pending && has_children) {
+            const Frame& f = frames[sp];
+            if (want_refl) {
+                rd = reflect(rd, normalv);  // reflectv (world.rs:92)
+                ro = over;
+                ++n_reflect;
+            } else {
+                ro = mk(f.rray[0], f.rray[1], f.rray[2]);
+                rd = mk(f.rray[3], f.rray[4], f.rray[5]);
+                ++n_refract;
             }
+            ++sp;
+            returning = false;
+        }
+        for (;;) {
+            // Pops frames while their colours are complete.  A lane ends the loop with a ray to trace
+            // (pending), with its subtree finished (pixel parked, or L_HOLDING), or blocked on a
+            // subtree another lane traces (L_WAITING).
             while (returning) {
                 if (sp == 0) {
-                    my_pixel[0] = value.x;
-                    my_pixel[1] = value.y;
-                    my_pixel[2] = value.z;
+                    if (SHARE && (job & L_HELPER)) {
+                        frames[0].refl[0] = value.x;  // free now: the colour waits here for its delivery
+                        frames[0].refl[1] = value.y;
+                        frames[0].refl[2] = value.z;
+                        job |= L_HOLDING;
+                    } else {
+                        my_pixel[0] = value.x;
+                        my_pixel[1] = value.y;
+                        my_pixel[2] = value.z;
+                    }
                     pending = false;
                     break;
                 }
                 Frame& f = frames[sp - 1];
-                if ((f.state & 1) == 0) {
+                if ((f.state & F_WAIT_REFR) == 0) {
                     // the reflected colour arrived (world.rs:228-230)
                     V3 refl = value * S.shade[f.node].refl;
-                    if (f.state & 2) {
+                    if (f.state & F_REFR_TODO) {
                         f.refl[0] = refl.x;
                         f.refl[1] = refl.y;
                         f.refl[2] = refl.z;
-                        f.state = (f.state & 4) | 1;
+                        if (SHARE && (f.state & F_HANDED)) {
+                            if (f.state & F_ARRIVED) {
+                                V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
+                                value = combine(f, L, refl, refr);
+                                --sp;
+                                continue;
+                            }
+                            f.state |= F_WAIT_REFR;
+                            job |= L_WAITING;  // nothing to trace until the other lane delivers
+                            pending = false;
+                            break;
+                        }
+                        f.state = (f.state & F_SCHLICK) | F_WAIT_REFR;
+                        if (SHARE) job &= ~(1 << (L_TODO_SHIFT + sp - 1));
                         ro = mk(f.rray[0], f.rray[1], f.rray[2]);
                         rd = mk(f.rray[3], f.rray[4], f.rray[5]);
                         ++n_refract;
+                        pending = true;
                         break;  // trace the refraction ray next
                     }
                     value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
@@ -1533,6 +1669,92 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                     value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
                 }
                 --sp;
+            }
+            returning = false;
+            if (!SHARE) break;
+            // ---- finished subtrees go back to the lanes that handed them over -------------------
+            const unsigned long long holders = wave_ballot((job & L_HOLDING) != 0);
+            if (holders == 0ull) break;
+            // The park area is free between the shadow walks; its rows serve as mail slots, one per
+            // receiving lane.  One colour per receiver and pass: when two subtrees of one lane finish
+            // together, one of them waits for the next pass.
+            int* const slot = reinterpret_cast<int*>(park[0]);
+            slot[lane] = -1;
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int to = (job >> L_FROM_SHIFT) & 63;
+            const int ticket = lane | (((job >> L_FRAME_SHIFT) & 7) << 8);
+            if (job & L_HOLDING) slot[to] = ticket;  // several writers: one of them lands
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if ((job & L_HOLDING) && slot[to] == ticket) {
+                park[1][to] = frames[0].refl[0];
+                park[2][to] = frames[0].refl[1];
+                park[3][to] = frames[0].refl[2];
+                job = 0;  // delivered: this lane is free again
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            const int got = slot[lane];
+            if (got >= 0) {
+                Frame& f = frames[got >> 8];
+                f.rray[0] = park[1][lane];
+                f.rray[1] = park[2][lane];
+                f.rray[2] = park[3][lane];
+                f.state |= F_ARRIVED;
+                if ((job & L_WAITING) && (got >> 8) == sp - 1) {
+                    // this lane was waiting for exactly this colour: go on popping
+                    job &= ~L_WAITING;
+                    V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
+                    value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                    --sp;
+                    returning = true;
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            if (wave_ballot(returning) == 0ull) break;
+        }
+        if (SHARE) {
+            // ---- lanes without work take over refraction subtrees of busy lanes --------------------
+            const bool offers = (job >> L_TODO_SHIFT) != 0;
+            const bool idle = !pending && (job & (L_WAITING | L_HOLDING)) == 0;
+            const unsigned long long offer_mask = wave_ballot(offers), idle_mask = wave_ballot(idle);
+            if (offer_mask != 0ull && idle_mask != 0ull) {
+                const int n_offer = __builtin_popcountll(offer_mask), n_idle = __builtin_popcountll(idle_mask);
+                const int n = n_offer < n_idle ? n_offer : n_idle;
+#ifdef RT_PROFILE_MIX
+                mix_handoffs += n;
+#endif
+                const unsigned long long below = (1ull << lane) - 1ull;
+                const int my_offer = __builtin_popcountll(offer_mask & below), my_idle = __builtin_popcountll(idle_mask & below);
+                int* const slot = reinterpret_cast<int*>(park[0]);
+                if (idle && my_idle < n) slot[my_idle] = lane;  // the k-th idle lane serves the k-th offer
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (offers && my_offer < n) {
+                    const int helper = slot[my_offer] & 63;
+                    // the oldest open frame: the largest subtree
+                    const int fi = __builtin_ctz((unsigned)(job >> L_TODO_SHIFT));
+                    Frame& f = frames[fi];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) park[1 + k][helper] = f.rray[k];
+                    reinterpret_cast<int*>(park[7])[helper] = ((job & L_DEPTH) + fi + 1) | (lane << L_FROM_SHIFT) | (fi << L_FRAME_SHIFT) | L_HELPER;
+                    f.state |= F_HANDED;
+                    job &= ~(1 << (L_TODO_SHIFT + fi));
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (idle && my_idle < n) {
+                    ro = mk(park[1][lane], park[2][lane], park[3][lane]);
+                    rd = mk(park[4][lane], park[5][lane], park[6][lane]);
+                    job = reinterpret_cast<int*>(park[7])[lane];
+                    sp = 0;
+                    pending = true;
+                    ++n_refract;
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
             }
         }
 #ifdef RT_PROFILE
@@ -1549,14 +1771,18 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     long long out_index;
     if (J.n_rays > 0) {
         out_index = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        rows = RT_TILE;
+        origin = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
     } else {
-        int px, local_y, lty;
-        lane_pixel(J, wave, lane, px, local_y, lty);
-        out_index = (long long)local_y * J.width + px;
+        int px, row_in_tile, lty;
+        lane_pixel(J, wave, lane, px, row_in_tile, lty, rows, origin);  // again: cheaper than keeping it in registers
+        out_index = origin + (long long)(lane >> 3) * J.width + (lane & 7);
     }
-    const bool whole_tile = J.wide_stores && wave_ballot(valid) == ~0ull;
+    // every pixel of the tile (or strip) is inside the frame: whole rows can be stored
+    const unsigned long long all_lanes = rows >= RT_TILE ? ~0ull : ((1ull << (rows * 8)) - 1ull);
+    const bool whole_tile = J.wide_stores && J.n_rays == 0 && wave_ballot(valid) == all_lanes;
     if (J.out_u8) {
-        // 24 bytes per tile row: the lanes' bytes are packed in LDS and 48 lanes store one dword each.
+        // 24 bytes per tile row: the lanes' bytes are packed in LDS and 6 lanes per row store one dword each.
         __shared__ unsigned tile8_lds[RT_BLOCK_WAVES][48];
         unsigned char* const t8 = reinterpret_cast<unsigned char*>(tile8_lds[wave]);
         unsigned char* const out8 = reinterpret_cast<unsigned char*>(out);
@@ -1567,9 +1793,8 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
             t8[lane * 3 + 2] = (unsigned char)b;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
-            if (lane < 48) {
+            if (lane < rows * 6) {
                 const int row = lane / 6, piece = lane % 6;
-                const long long origin = out_index - (lane & 7) - (long long)(lane >> 3) * J.width;  // this lane's tile origin
                 *reinterpret_cast<unsigned*>(out8 + (origin + (long long)row * J.width) * 3 + piece * 4) =
                     tile8_lds[wave][lane];
             }
@@ -1582,10 +1807,9 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         const double* t = tile_lds[wave];
         // rows of the tile are 8 pixels apart in the lane order, so the LDS image is already
         // [row][192 bytes]; piece c (16 bytes) belongs to row c / 12, byte offset (c % 12) * 16
-        const long long row_stride = (long long)J.width * 3;                    // doubles
-        const long long base = (out_index - (lane & 7) - (long long)(lane >> 3) * J.width) * 3;  // tile origin
-#pragma unroll
-        for (int c = lane; c < 96; c += 64) {
+        const long long row_stride = (long long)J.width * 3;  // doubles
+        const long long base = origin * 3;
+        for (int c = lane; c < rows * 12; c += 64) {
             const int row = c / 12, piece = c % 12;
             double2 v = *reinterpret_cast<const double2*>(t + row * 24 + piece * 2);
             *reinterpret_cast<double2*>(out + base + row * row_stride + piece * 2) = v;
@@ -1610,6 +1834,15 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         atomicAdd(&counters[11], prof_prepare);
         atomicAdd(&counters[12], prof_light);
         atomicAdd(&counters[13], prof_return);
+    }
+#endif
+#ifdef RT_PROFILE_MIX
+    if (lane == 0) {
+        for (int k = 0; k < 8; ++k) atomicAdd(&counters[4 + k], mix[k]);
+        atomicAdd(&counters[12], mix_rounds);
+        atomicAdd(&counters[13], mix_handoffs);
+        atomicAdd(&counters[14], mix_lane_rounds);
+        atomicMax(&counters[15], mix_rounds);
     }
 #endif
     unsigned c[4] = {n_primary, n_shadow, n_reflect, n_refract};
@@ -2426,6 +2659,7 @@ constexpr long long ORDER_MIN_TILES = 4096;
 // fixed: null, or this device's static scratch (rt_render_device_static): the launch then uses the
 // counter set and the order arrays in it and allocates nothing.
 int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t stream, unsigned char* fixed = nullptr) {
+    // blocks: one per tile (or per 64 caller-supplied rays); strips of class-2 tiles are added below
     int slot = (int)(s->launches % TIMING_RING);
     // Launches on one scene must be ordered (one stream at a time): each clears the other counter set.
     const int a = s->next_set, b = a ^ 1;
@@ -2458,16 +2692,41 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
         job.tile_order = order;
         job.tile_class_count = mine + COUNTER_WORDS;
     }
+    // Tiles whose centre ray meets a transparent surface (class 2) are rendered in strips, one
+    // wavefront each, so that most lanes of those wavefronts start without a pixel and take over
+    // refraction subtrees (see L_*): the frame's longest wavefront gets shorter.  More strips mean
+    // more lanes to share with and more wavefronts in total: four for small frames, whose time is
+    // that of their longest wavefront, two for large ones.  RT_SPLIT=1, 2 or 4 overrides (diagnostic).
+    job.split = 1;
+    job.extra_blocks = 0;
+    bool share = false;
+    if (job.tile_order && s->any_transparent && !s->any_csg) {
+        static const int split_env = getenv("RT_SPLIT") ? atoi(getenv("RT_SPLIT")) : 0;
+        // measured on the default scene: 8,100 tiles 0.42 -> 0.26 ms with four strips, 32,400 tiles
+        // 0.47 -> 0.35 ms with two; at 129,600 tiles and beyond strips only add work
+        int split = split_env ? split_env : (tiles >= 65536 ? 1 : (tiles >= 16384 ? 2 : 4));
+        if (split != 1 && split != 2 && split != 4) split = 1;
+        if (split > 1) {
+            const long long cap = tiles / 8 > 1024 ? tiles / 8 : 1024;  // beyond that many extra strips: whole tiles
+            job.split = split;
+            job.extra_blocks = tiles * (split - 1) < cap ? tiles * (split - 1) : cap;
+            if ((long long)blocks + job.extra_blocks > 0x7fffffffLL) job.split = 1, job.extra_blocks = 0;
+            blocks += (unsigned)job.extra_blocks;
+            share = job.split > 1;
+        }
+    }
     HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (job.tile_order) {
         DevJob pre = job;
         pre.tile_order = nullptr;
-        using Pre = void (*)(DevScene, DevJob, long long, int*);
+        using Pre = void (*)(DevScene, DevJob, long long, int, int*);
         static const Pre pres[4] = {tile_class_kernel<false, false, false>, tile_class_kernel<false, true, false>,
                                     tile_class_kernel<true, false, false>, tile_class_kernel<true, true, false>};
         Pre prek = s->any_csg ? tile_class_kernel<true, true, true> : pres[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
         int* classes = order + 3 * tiles;
-        hipLaunchKernelGGL(prek, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, s->dev, pre, tiles, classes);
+        static const int probe_env = getenv("RT_PROBE") ? atoi(getenv("RT_PROBE")) : 2;  // diagnostic
+        const int probe = share ? probe_env : 0;  // mirrors only matter for the strips
+        hipLaunchKernelGGL(prek, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, s->dev, pre, tiles, probe, classes);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)((tiles + ORDER_BLOCK - 1) / ORDER_BLOCK)), dim3(ORDER_BLOCK), 0, stream, job.tiles_x,
                            job.local_tile_rows, tiles, (const int*)classes, order, mine + COUNTER_WORDS);
@@ -2481,6 +2740,9 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
             rt_kernel<true, false, false, false>,  rt_kernel<true, false, true, false>,
             rt_kernel<true, true, false, false>,   rt_kernel<true, true, true, false>};
         Kernel kernel = kernels[(s->any_transparent ? 4 : 0) | (s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
+        static const Kernel sharing[4] = {rt_kernel<true, false, false, false, true>, rt_kernel<true, false, true, false, true>,
+                                          rt_kernel<true, true, false, false, true>, rt_kernel<true, true, true, false, true>};
+        if (share) kernel = sharing[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
         // scenes with CSG shapes are rare: they share the two most general variants
         if (s->any_csg) kernel = s->any_transparent ? rt_kernel<true, true, true, true> : rt_kernel<false, true, true, true>;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, mine,
@@ -2513,6 +2775,24 @@ int fill_stats(rt_scene* s, rt_stats* st) {
     st->rays_refract = c[3];
     st->kernel_ms = 0.0f;
     st->reserved = 0.0f;
+#ifdef RT_PROFILE_MIX
+    {
+        unsigned long long cls[3] = {0, 0, 0};
+        (void)hipMemcpy(cls, (s->last_counters ? s->last_counters : s->d_counters) + COUNTER_WORDS, sizeof cls, hipMemcpyDeviceToHost);
+        fprintf(stderr, "RT_PROFILE_MIX tiles per class: %llu %llu %llu\n", cls[0], cls[1], cls[2]);
+        if (s->d_order && s->order_cap > 0) {
+            std::vector<int> raw((size_t)s->order_cap);
+            (void)hipMemcpy(raw.data(), s->d_order + 3 * s->order_cap, raw.size() * sizeof(int), hipMemcpyDeviceToHost);
+            long long hist[4] = {0, 0, 0, 0};
+            for (int v : raw) ++hist[v < 0 || v > 2 ? 3 : v];
+            fprintf(stderr, "RT_PROFILE_MIX centre-ray classes: %lld %lld %lld (other %lld)\n", hist[0], hist[1], hist[2], hist[3]);
+        }
+        unsigned long long most = 0;
+        for (unsigned k = 0; k < COUNTER_SHARDS; ++k) most = shards[k * 16 + 15] > most ? shards[k * 16 + 15] : most;
+        fprintf(stderr, "RT_PROFILE_MIX cull=%llu cull_lanes=%llu group=%llu group_lanes=%llu leaf=%llu leaf_lanes=%llu leaf_idle=%llu walks=%llu rounds=%llu handoffs=%llu lane_rounds=%llu longest_wave_rounds=%llu\n",
+                c[4], c[5], c[6], c[7], c[8], c[9], c[10], c[11], c[12], c[13], c[14], most);
+    }
+#endif
 #ifdef RT_PROFILE
     {
         const unsigned long long* pc = c;
