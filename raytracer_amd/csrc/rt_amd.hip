@@ -1347,8 +1347,6 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     bool pending;  // this lane has a ray to trace in the coming round
     bool valid;    // this lane owns a pixel (or a caller-supplied ray) and stores its colour
     V3 ro, rd;
-    int rows = RT_TILE;     // rows of the tile this wavefront renders (fewer for a strip of a class-2 tile)
-    long long origin = 0;   // first pixel of the tile or strip in the output
     if (J.n_rays > 0) {
         // World::color_at for caller-supplied rays.
         long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1357,7 +1355,8 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         ro = mk(J.ray_o[rr * 3], J.ray_o[rr * 3 + 1], J.ray_o[rr * 3 + 2]);
         rd = mk(J.ray_d[rr * 3], J.ray_d[rr * 3 + 1], J.ray_d[rr * 3 + 2]);
     } else {
-        int px, row_in_tile, lty;
+        int px, row_in_tile, lty, rows;  // rows of the tile this wavefront renders (fewer for a strip of a class-2 tile)
+        long long origin;
         lane_pixel(J, wave, lane, px, row_in_tile, lty, rows, origin);
         const int py = (lty * J.world_size + J.rank) * RT_TILE + row_in_tile;
         pending = (lane >> 3) < rows && lty < J.local_tile_rows && px < J.width && py < J.height;
@@ -1599,121 +1598,171 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         unsigned long long pr0 = __builtin_amdgcn_s_memtime();
 #endif
         // ---- suspend, or return the colour up the stack ----------------------------------------
-        V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
-        bool returning = pending;
-        if (pending && has_children) {
-            const Frame& f = frames[sp];
-            if (want_refl) {
-                rd = reflect(rd, normalv);  // reflectv (world.rs:92)
-                ro = over;
-                ++n_reflect;
-            } else {
-                ro = mk(f.rray[0], f.rray[1], f.rray[2]);
-                rd = mk(f.rray[3], f.rray[4], f.rray[5]);
-                ++n_refract;
-            }
-            ++sp;
-            returning = false;
-        }
-        for (;;) {
-            // Pops frames while their colours are complete.  A lane ends the loop with a ray to trace
-            // (pending), with its subtree finished (pixel parked, or L_HOLDING), or blocked on a
-            // subtree another lane traces (L_WAITING).
-            while (returning) {
-                if (sp == 0) {
-                    if (SHARE && (job & L_HELPER)) {
-                        frames[0].refl[0] = value.x;  // free now: the colour waits here for its delivery
-                        frames[0].refl[1] = value.y;
-                        frames[0].refl[2] = value.z;
-                        job |= L_HOLDING;
+        if constexpr (!SHARE) {
+            if (pending) {
+                V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
+                bool returning = true;
+                if (has_children) {
+                    const Frame& f = frames[sp];
+                    if (want_refl) {
+                        rd = reflect(rd, normalv);  // reflectv (world.rs:92)
+                        ro = over;
+                        ++n_reflect;
                     } else {
-                        my_pixel[0] = value.x;
-                        my_pixel[1] = value.y;
-                        my_pixel[2] = value.z;
-                    }
-                    pending = false;
-                    break;
-                }
-                Frame& f = frames[sp - 1];
-                if ((f.state & F_WAIT_REFR) == 0) {
-                    // the reflected colour arrived (world.rs:228-230)
-                    V3 refl = value * S.shade[f.node].refl;
-                    if (f.state & F_REFR_TODO) {
-                        f.refl[0] = refl.x;
-                        f.refl[1] = refl.y;
-                        f.refl[2] = refl.z;
-                        if (SHARE && (f.state & F_HANDED)) {
-                            if (f.state & F_ARRIVED) {
-                                V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
-                                value = combine(f, L, refl, refr);
-                                --sp;
-                                continue;
-                            }
-                            f.state |= F_WAIT_REFR;
-                            job |= L_WAITING;  // nothing to trace until the other lane delivers
-                            pending = false;
-                            break;
-                        }
-                        f.state = (f.state & F_SCHLICK) | F_WAIT_REFR;
-                        if (SHARE) job &= ~(1 << (L_TODO_SHIFT + sp - 1));
                         ro = mk(f.rray[0], f.rray[1], f.rray[2]);
                         rd = mk(f.rray[3], f.rray[4], f.rray[5]);
                         ++n_refract;
-                        pending = true;
-                        break;  // trace the refraction ray next
                     }
-                    value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
-                } else {
-                    // the refracted colour arrived (world.rs:274)
-                    V3 refr = value * S.shade[f.node].transp;
-                    value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                    ++sp;
+                    returning = false;
                 }
-                --sp;
-            }
-            returning = false;
-            if (!SHARE) break;
-            // ---- finished subtrees go back to the lanes that handed them over -------------------
-            const unsigned long long holders = wave_ballot((job & L_HOLDING) != 0);
-            if (holders == 0ull) break;
-            // The park area is free between the shadow walks; its rows serve as mail slots, one per
-            // receiving lane.  One colour per receiver and pass: when two subtrees of one lane finish
-            // together, one of them waits for the next pass.
-            int* const slot = reinterpret_cast<int*>(park[0]);
-            slot[lane] = -1;
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            const int to = (job >> L_FROM_SHIFT) & 63;
-            const int ticket = lane | (((job >> L_FRAME_SHIFT) & 7) << 8);
-            if (job & L_HOLDING) slot[to] = ticket;  // several writers: one of them lands
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            if ((job & L_HOLDING) && slot[to] == ticket) {
-                park[1][to] = frames[0].refl[0];
-                park[2][to] = frames[0].refl[1];
-                park[3][to] = frames[0].refl[2];
-                job = 0;  // delivered: this lane is free again
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            const int got = slot[lane];
-            if (got >= 0) {
-                Frame& f = frames[got >> 8];
-                f.rray[0] = park[1][lane];
-                f.rray[1] = park[2][lane];
-                f.rray[2] = park[3][lane];
-                f.state |= F_ARRIVED;
-                if ((job & L_WAITING) && (got >> 8) == sp - 1) {
-                    // this lane was waiting for exactly this colour: go on popping
-                    job &= ~L_WAITING;
-                    V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
-                    value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                while (returning) {
+                    if (sp == 0) {
+                        my_pixel[0] = value.x;
+                        my_pixel[1] = value.y;
+                        my_pixel[2] = value.z;
+                        pending = false;
+                        break;
+                    }
+                    Frame& f = frames[sp - 1];
+                    if ((f.state & F_WAIT_REFR) == 0) {
+                        // the reflected colour arrived (world.rs:228-230)
+                        V3 refl = value * S.shade[f.node].refl;
+                        if (f.state & F_REFR_TODO) {
+                            f.refl[0] = refl.x;
+                            f.refl[1] = refl.y;
+                            f.refl[2] = refl.z;
+                            f.state = (f.state & F_SCHLICK) | F_WAIT_REFR;
+                            ro = mk(f.rray[0], f.rray[1], f.rray[2]);
+                            rd = mk(f.rray[3], f.rray[4], f.rray[5]);
+                            ++n_refract;
+                            break;  // trace the refraction ray next
+                        }
+                        value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
+                    } else {
+                        // the refracted colour arrived (world.rs:274)
+                        V3 refr = value * S.shade[f.node].transp;
+                        value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                    }
                     --sp;
-                    returning = true;
                 }
             }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            if (wave_ballot(returning) == 0ull) break;
+        } else {
+            V3 value = acc;  // (0,0,0) when nothing was hit (world.rs:211)
+            bool returning = pending;
+            if (pending && has_children) {
+                const Frame& f = frames[sp];
+                if (want_refl) {
+                    rd = reflect(rd, normalv);  // reflectv (world.rs:92)
+                    ro = over;
+                    ++n_reflect;
+                } else {
+                    ro = mk(f.rray[0], f.rray[1], f.rray[2]);
+                    rd = mk(f.rray[3], f.rray[4], f.rray[5]);
+                    ++n_refract;
+                }
+                ++sp;
+                returning = false;
+            }
+            for (;;) {
+                // Pops frames while their colours are complete.  A lane ends the loop with a ray to trace
+                // (pending), with its subtree finished (pixel parked, or L_HOLDING), or blocked on a
+                // subtree another lane traces (L_WAITING).
+                while (returning) {
+                    if (sp == 0) {
+                        if (SHARE && (job & L_HELPER)) {
+                            frames[0].refl[0] = value.x;  // free now: the colour waits here for its delivery
+                            frames[0].refl[1] = value.y;
+                            frames[0].refl[2] = value.z;
+                            job |= L_HOLDING;
+                        } else {
+                            my_pixel[0] = value.x;
+                            my_pixel[1] = value.y;
+                            my_pixel[2] = value.z;
+                        }
+                        pending = false;
+                        break;
+                    }
+                    Frame& f = frames[sp - 1];
+                    if ((f.state & F_WAIT_REFR) == 0) {
+                        // the reflected colour arrived (world.rs:228-230)
+                        V3 refl = value * S.shade[f.node].refl;
+                        if (f.state & F_REFR_TODO) {
+                            f.refl[0] = refl.x;
+                            f.refl[1] = refl.y;
+                            f.refl[2] = refl.z;
+                            if (SHARE && (f.state & F_HANDED)) {
+                                if (f.state & F_ARRIVED) {
+                                    V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
+                                    value = combine(f, L, refl, refr);
+                                    --sp;
+                                    continue;
+                                }
+                                f.state |= F_WAIT_REFR;
+                                job |= L_WAITING;  // nothing to trace until the other lane delivers
+                                pending = false;
+                                break;
+                            }
+                            f.state = (f.state & F_SCHLICK) | F_WAIT_REFR;
+                            if (SHARE) job &= ~(1 << (L_TODO_SHIFT + sp - 1));
+                            ro = mk(f.rray[0], f.rray[1], f.rray[2]);
+                            rd = mk(f.rray[3], f.rray[4], f.rray[5]);
+                            ++n_refract;
+                            pending = true;
+                            break;  // trace the refraction ray next
+                        }
+                        value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
+                    } else {
+                        // the refracted colour arrived (world.rs:274)
+                        V3 refr = value * S.shade[f.node].transp;
+                        value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                    }
+                    --sp;
+                }
+                returning = false;
+                    // ---- finished subtrees go back to the lanes that handed them over -------------------
+                const unsigned long long holders = wave_ballot((job & L_HOLDING) != 0);
+                if (holders == 0ull) break;
+                // The park area is free between the shadow walks; its rows serve as mail slots, one per
+                // receiving lane.  One colour per receiver and pass: when two subtrees of one lane finish
+                // together, one of them waits for the next pass.
+                int* const slot = reinterpret_cast<int*>(park[0]);
+                slot[lane] = -1;
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int to = (job >> L_FROM_SHIFT) & 63;
+                const int ticket = lane | (((job >> L_FRAME_SHIFT) & 7) << 8);
+                if (job & L_HOLDING) slot[to] = ticket;  // several writers: one of them lands
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if ((job & L_HOLDING) && slot[to] == ticket) {
+                    park[1][to] = frames[0].refl[0];
+                    park[2][to] = frames[0].refl[1];
+                    park[3][to] = frames[0].refl[2];
+                    job = 0;  // delivered: this lane is free again
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                const int got = slot[lane];
+                if (got >= 0) {
+                    Frame& f = frames[got >> 8];
+                    f.rray[0] = park[1][lane];
+                    f.rray[1] = park[2][lane];
+                    f.rray[2] = park[3][lane];
+                    f.state |= F_ARRIVED;
+                    if ((job & L_WAITING) && (got >> 8) == sp - 1) {
+                        // this lane was waiting for exactly this colour: go on popping
+                        job &= ~L_WAITING;
+                        V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
+                        value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                        --sp;
+                        returning = true;
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);
+                __builtin_amdgcn_wave_barrier();
+                if (wave_ballot(returning) == 0ull) break;
+            }
         }
         if (SHARE) {
             // ---- lanes without work take over refraction subtrees of busy lanes --------------------
@@ -1769,9 +1818,10 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
     __builtin_amdgcn_wave_barrier();
     long long out_index;
+    int rows = RT_TILE;    // rows of the tile this wavefront stores
+    long long origin = 0;  // first pixel of the tile or strip in the output
     if (J.n_rays > 0) {
         out_index = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        rows = RT_TILE;
         origin = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
     } else {
         int px, row_in_tile, lty;
@@ -1809,8 +1859,15 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         // [row][192 bytes]; piece c (16 bytes) belongs to row c / 12, byte offset (c % 12) * 16
         const long long row_stride = (long long)J.width * 3;  // doubles
         const long long base = origin * 3;
-        for (int c = lane; c < rows * 12; c += 64) {
-            const int row = c / 12, piece = c % 12;
+        if (rows == RT_TILE) {
+#pragma unroll
+            for (int c = lane; c < RT_TILE * 12; c += 64) {
+                const int row = c / 12, piece = c % 12;
+                double2 v = *reinterpret_cast<const double2*>(t + row * 24 + piece * 2);
+                *reinterpret_cast<double2*>(out + base + row * row_stride + piece * 2) = v;
+            }
+        } else if (lane < rows * 12) {  // a strip: at most four rows, 48 pieces
+            const int row = lane / 12, piece = lane % 12;
             double2 v = *reinterpret_cast<const double2*>(t + row * 24 + piece * 2);
             *reinterpret_cast<double2*>(out + base + row * row_stride + piece * 2) = v;
         }
