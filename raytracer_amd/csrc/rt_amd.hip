@@ -86,8 +86,8 @@ static_assert(sizeof(TRec) == 128, "traversal record must be 128 bytes");
 enum { S_HAS_XFORM = 1, S_CASTS_SHADOW = 2, S_SOLID = 4 };
 struct alignas(16) SRec {
     int type, flags, pattern, n_levels;  // n_levels: the leaf plus all its ancestors
-    int anc_xf[4];                       // transforms of the transformed ancestors, nearest first, -1 padded
-    int anc_level[4];                    // how many levels above the leaf each of them is
+    int anc_xf[RT_MAX_XFORM_NEST];                       // transforms of the transformed ancestors, nearest first, -1 padded
+    int anc_level[RT_MAX_XFORM_NEST];                    // how many levels above the leaf each of them is
     int tri, pad0, pad1, pad2;           // triangle normals index
     double inv[12];                      // the leaf's own inverse rows / transposed 3x3 (S_HAS_XFORM)
     double inv_t[9];
@@ -96,7 +96,7 @@ struct alignas(16) SRec {
     double r0, r1;                       // cylinder / cone range
     double pad3;
 };
-static_assert(sizeof(SRec) == 336, "shading record layout");
+static_assert(sizeof(SRec) == 304 + 8 * RT_MAX_XFORM_NEST && sizeof(SRec) % 16 == 0, "shading record layout");
 
 struct DevScene {
     const RT_CONST SRec* shade;
@@ -1101,8 +1101,9 @@ DI unsigned clamp_u8(double c) {
 
 // One suspended color_at call that is waiting for its reflected / refracted colour
 // (World::shade_hit, world.rs:162-196).
+// The surface colours of the frame (one per light, in light order) are kept beside it, packed by the
+// scene's number of lights: see `surfs` in rt_kernel.
 struct Frame {
-    double surf[RT_MAX_LIGHTS][3];  // surface colour per light, in light order
     double refl[3];                 // reflected colour * reflective (written once it is known)
     double rray[6];                 // pending refraction ray (under_point, direction); only with a refraction.  Once the
                                     // refraction has been handed to another lane, rray[0..2] receives its colour.
@@ -1134,13 +1135,13 @@ enum { L_DEPTH = 7, L_FROM_SHIFT = 3, L_FRAME_SHIFT = 9, L_HELPER = 1 << 12, L_W
        L_TODO_SHIFT = 16 };
 
 // ((acc + surface) + reflected [* k]) + refracted [* (1 - k)] per light, world.rs:183-192.
-DI V3 combine(const Frame& f, int n_lights, V3 refl, V3 refr) {
+DI V3 combine(const Frame& f, const double* surf, int n_lights, V3 refl, V3 refr) {
     V3 acc = mk(0.0, 0.0, 0.0);
     const bool use_k = (f.state & 4) != 0;
     V3 a = use_k ? refl * f.k : refl;
     V3 b = use_k ? refr * (1.0 - f.k) : refr;
     for (int l = 0; l < n_lights; ++l) {
-        V3 s = mk(f.surf[l][0], f.surf[l][1], f.surf[l][2]);
+        V3 s = mk(surf[l * 3], surf[l * 3 + 1], surf[l * 3 + 2]);
         acc = acc + s + a + b;
     }
     return acc;
@@ -1367,6 +1368,9 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
 
     unsigned n_primary = pending ? 1u : 0u, n_shadow = 0u, n_reflect = 0u, n_refract = 0u;
     Frame frames[RT_MAX_FRAMES];
+    // Surface colours of the suspended calls: frame i, light l at (i * L + l) * 3.  Packed by the
+    // scene's light count, so that a two-light scene touches 48 bytes per frame whatever the limit is.
+    double surfs[RT_MAX_FRAMES * RT_MAX_LIGHTS * 3];
     int sp = 0;  // suspended calls of this lane's subtree; the ray being traced has remaining = max_depth - depth - sp
     const int L = S.n_lights;
 
@@ -1584,9 +1588,10 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                     surf = ambient + diffuse + specular;
                 }
                 if (has_children) {
-                    frames[sp].surf[l][0] = surf.x;
-                    frames[sp].surf[l][1] = surf.y;
-                    frames[sp].surf[l][2] = surf.z;
+                    double* const fs = surfs + (sp * L + l) * 3;
+                    fs[0] = surf.x;
+                    fs[1] = surf.y;
+                    fs[2] = surf.z;
                 } else {
                     acc = acc + surf;  // + black + black: exact no-ops (world.rs:191)
                 }
@@ -1638,11 +1643,11 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                             ++n_refract;
                             break;  // trace the refraction ray next
                         }
-                        value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
+                        value = combine(f, surfs + (sp - 1) * L * 3, L, refl, mk(0.0, 0.0, 0.0));
                     } else {
                         // the refracted colour arrived (world.rs:274)
                         V3 refr = value * S.shade[f.node].transp;
-                        value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                        value = combine(f, surfs + (sp - 1) * L * 3, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
                     }
                     --sp;
                 }
@@ -1694,7 +1699,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                             if (SHARE && (f.state & F_HANDED)) {
                                 if (f.state & F_ARRIVED) {
                                     V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
-                                    value = combine(f, L, refl, refr);
+                                    value = combine(f, surfs + (sp - 1) * L * 3, L, refl, refr);
                                     --sp;
                                     continue;
                                 }
@@ -1711,11 +1716,11 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                             pending = true;
                             break;  // trace the refraction ray next
                         }
-                        value = combine(f, L, refl, mk(0.0, 0.0, 0.0));
+                        value = combine(f, surfs + (sp - 1) * L * 3, L, refl, mk(0.0, 0.0, 0.0));
                     } else {
                         // the refracted colour arrived (world.rs:274)
                         V3 refr = value * S.shade[f.node].transp;
-                        value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                        value = combine(f, surfs + (sp - 1) * L * 3, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
                     }
                     --sp;
                 }
@@ -1754,7 +1759,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                         // this lane was waiting for exactly this colour: go on popping
                         job &= ~L_WAITING;
                         V3 refr = mk(f.rray[0], f.rray[1], f.rray[2]) * S.shade[f.node].transp;  // world.rs:274
-                        value = combine(f, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
+                        value = combine(f, surfs + (sp - 1) * L * 3, L, mk(f.refl[0], f.refl[1], f.refl[2]), refr);
                         --sp;
                         returning = true;
                     }
@@ -2651,13 +2656,13 @@ std::vector<SRec> build_shade_records(const rt_scene_desc* d) {
         r.flags = (n.flags & RT_NODE_CASTS_SHADOW) ? S_CASTS_SHADOW : 0;
         r.pattern = -1;
         r.tri = (n.type == RT_TRIANGLE || n.type == RT_SMOOTH_TRIANGLE) ? n.data : -1;
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < RT_MAX_XFORM_NEST; ++k) {
             r.anc_xf[k] = -1;
             r.anc_level[k] = 0;
         }
         int levels = 1, found = 0;
         for (int p = n.parent; p >= 0; p = d->nodes[p].parent) {
-            if (d->nodes[p].xform >= 0 && found < 4) {
+            if (d->nodes[p].xform >= 0 && found < RT_MAX_XFORM_NEST) {
                 r.anc_xf[found] = d->nodes[p].xform;
                 r.anc_level[found] = levels;
                 ++found;

@@ -88,7 +88,7 @@ def test_multi_create_validates_before_it_needs_a_gpu(host):
     if lib.rt_device_count() == 0:
         assert rc == abi.RT_ERR_NO_DEVICE and not handle
         broken = abi.rt_scene_desc.from_buffer_copy(desc)
-        broken.n_lights = 5
+        broken.n_lights = abi.RT_MAX_LIGHTS + 1
         assert lib.rt_multi_create(C.byref(broken), 1, None, C.byref(handle)) == abi.RT_ERR_LIMIT
     else:
         assert rc == abi.RT_OK
@@ -181,7 +181,7 @@ def test_scene_create_rejects_malformed_tables(host):
     nodes[5].ctx = 1
     assert create(broken) == abi.RT_ERR_INVALID
     nodes[5].ctx = -1
-    broken.n_lights = 5
+    broken.n_lights = abi.RT_MAX_LIGHTS + 1
     assert create(broken) == abi.RT_ERR_LIMIT
     assert lib.rt_scene_create(None, 0, C.byref(handle)) == abi.RT_ERR_INVALID
 
@@ -250,12 +250,14 @@ def test_csg_nodes_flatten_and_validate(host):
         for k in range(n):
             shape = host.CSG(host.UNION, shape, host.Sphere(M.translation(0.1 * (k + 1), 0, 0), host.Phong.default(), True))
         return shape
-    ok = host.scene_desc(host.World([chain(4)], []))
+    ok = host.scene_desc(host.World([chain(abi.RT_MAX_CSG_NEST)], []))
     assert create(ok) in (abi.RT_OK, abi.RT_ERR_NO_DEVICE)
-    deep = host.scene_desc(host.World([chain(5)], []))
+    deep = host.scene_desc(host.World([chain(abi.RT_MAX_CSG_NEST + 1)], []))
     assert create(deep) == abi.RT_ERR_LIMIT and b"nested" in lib.rt_last_error()
-    wide = host.Group()
-    for k in range(13):
-        wide.add_child(host.Sphere(M.translation(0.1 * k, 0, 0), host.Phong.default(), True))
-    many = host.scene_desc(host.World([host.CSG(host.UNION, wide, host.Sphere(M.identity(), host.Phong.default(), True))], []))
-    assert create(many) == abi.RT_ERR_LIMIT and b"intersections" in lib.rt_last_error()
+    def wide(n):
+        g = host.Group()
+        for k in range(n):
+            g.add_child(host.Sphere(M.translation(0.1 * k, 0, 0), host.Phong.default(), True))
+        return host.scene_desc(host.World([host.CSG(host.UNION, g, host.Sphere(M.identity(), host.Phong.default(), True))], []))
+    assert create(wide(13)) in (abi.RT_OK, abi.RT_ERR_NO_DEVICE)      # 28 intersections at most
+    assert create(wide(abi.RT_MAX_CSG_HITS // 2)) == abi.RT_ERR_LIMIT and b"intersections" in lib.rt_last_error()

@@ -155,10 +155,10 @@ def test_csg_limits_are_reported(host):
     cam = host.Camera(8, 8, 1.0, M.identity())
     light = [host.PointLight(host.point(0, 5, -5), host.Color.white())]
     with pytest.raises(abi.RtError) as e:
-        host.render(host.World([chain(5)], light), cam)   # 5 nested CSG shapes > RT_MAX_CSG_NEST
+        host.render(host.World([chain(abi.RT_MAX_CSG_NEST + 1)], light), cam)   # one more nested CSG shape than allowed
     assert e.value.code == abi.RT_ERR_LIMIT
     wide = host.Group()
-    for k in range(13):                                    # 26 intersections > RT_MAX_CSG_HITS
+    for k in range(abi.RT_MAX_CSG_HITS // 2):              # with the right operand: more intersections than RT_MAX_CSG_HITS
         wide.add_child(host.Sphere(M.translation(0.1 * k, 0, 0), host.Phong.default(), True))
     with pytest.raises(abi.RtError) as e:
         host.render(host.World([host.CSG(host.UNION, wide, host.Sphere(M.identity(), host.Phong.default(), True))], light), cam)

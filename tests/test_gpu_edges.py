@@ -61,10 +61,11 @@ def test_ranks_without_rows(host):
 
 def test_depth_zero_and_limits(host, orc):
     make = lambda api, n: api.World(some_objects(api), [light(api, k) for k in range(n)])
-    img = host.render(make(host, 4), camera(host, 32, 20), max_depth=0)      # four lights: the most allowed
-    ref = orc.render(make(orc, 4), camera(orc, 32, 20), remaining=0)
+    most = abi.RT_MAX_LIGHTS
+    img = host.render(make(host, most), camera(host, 32, 20), max_depth=0)   # as many lights as are allowed
+    ref = orc.render(make(orc, most), camera(orc, 32, 20), remaining=0)
     assert np.abs(img - ref).max() <= 1e-11
     with pytest.raises(abi.RtError):
-        host.render(make(host, 5), camera(host, 32, 20))
+        host.render(make(host, most + 1), camera(host, 32, 20))
     with pytest.raises(abi.RtError):
         host.render(make(host, 1), camera(host, 32, 20), max_depth=6)

@@ -1,0 +1,106 @@
+"""Scenes beyond what the first version of the device path accepted (4 lights, 4 nested transformed
+groups, 4 nested gradient/blended patterns, 24 intersections per CSG shape): the reference has no such
+limits (its recursion and its Vec<Intersection> grow as needed), and up to the documented sizes of
+include/rt_abi.h neither has the device path.  Every pixel against the oracle."""
+import math
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi
+
+pytestmark = pytest.mark.gpu
+
+
+def camera(api, W, H, frm=(0, 2.5, -9), to=(0, 1, 0)):
+    return api.Camera(H, W, 1.0, api.Matrix.view_transform(api.point(*frm), api.point(*to), api.vector(0, 1, 0)))
+
+
+def check(host, orc, make, W=200, H=120, **cam):
+    img, st = host.render(make(host), camera(host, W, H, **cam), stats=True)
+    ref, cnt = orc.render(make(orc), camera(orc, W, H, **cam), counters=True)
+    assert ref.any() and np.isfinite(ref).all()
+    assert np.abs(img - ref).max() <= 1e-11
+    assert (st.rays_shadow, st.rays_reflect, st.rays_refract) == (cnt["rays_shadow"], cnt["rays_reflect"], cnt["rays_refract"])
+    return img
+
+
+def test_six_lights_with_reflection_and_refraction(host, orc):
+    """Six lights: the reflected and refracted colours are re-added once per light (world.rs:180-192),
+    so a frame keeps six surface colours."""
+    def make(api):
+        M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+        floor = api.Plane(M.identity(), Phong(api.Checker(Solid(Color.white()), Solid(Color(0.2, 0.2, 0.2)), M.identity()),
+                                              0.1, 0.8, 0.1, 50.0, 0.3, 0.0, 1.0), True)
+        glass = api.Sphere(M.translation(-1.2, 1, 0), Phong(Solid(Color(0.05, 0.05, 0.1)), 0.0, 0.1, 0.9, 200.0, 0.6, 0.8, 1.5), True)
+        mirror = api.Cube(M.translation(1.4, 0.8, 0.5) * M.rotation_y(0.5) * M.scaling(0.8, 0.8, 0.8),
+                          Phong(Solid(Color(0.7, 0.3, 0.2)), 0.1, 0.6, 0.5, 80.0, 0.5, 0.0, 1.0), True)
+        lights = [api.PointLight(api.point(-8 + 3 * k, 6 + (k % 3), -7 + (k % 2) * 3), Color(0.25, 0.2 + 0.02 * k, 0.22))
+                  for k in range(6)]
+        return api.World([floor, glass, mirror], lights)
+    check(host, orc, make)
+
+
+def test_six_nested_transformed_groups(host, orc):
+    """A leaf under six groups that each carry their own transform: the ray is taken through six
+    inverses on the way down, the normal through six inverse transposes (with a renormalisation at each
+    level, shape.rs:83-98) on the way up."""
+    def make(api):
+        M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+        mat = Phong(api.Striped(Solid(Color(0.9, 0.4, 0.2)), Solid(Color(0.2, 0.4, 0.9)), M.scaling(0.3, 0.3, 0.3)),
+                    0.1, 0.8, 0.4, 60.0, 0.2, 0.0, 1.0)
+        inner = api.Group(M.rotation_z(0.2) * M.scaling(1.1, 0.9, 1.0))
+        inner.add_child(api.Sphere(M.translation(0.3, 0, 0), mat, True))
+        inner.add_child(api.Cylinder(M.translation(-1.0, -0.5, 0.2) * M.scaling(0.4, 1, 0.4), mat, True, 0.0, 1.5, True))
+        inner.add_child(api.SmoothTriangle(api.point(0, 1.2, 0), api.point(-0.8, 0.2, 0.1), api.point(0.8, 0.2, 0.1),
+                                           api.vector(0, 1, -0.3), api.vector(-0.5, 0.2, -0.8), api.vector(0.5, 0.2, -0.8),
+                                           M.translation(0, 0.6, -0.4), mat, True))
+        g = inner
+        steps = [M.translation(0.2, 0.1, 0), M.rotation_y(0.3), M.scaling(0.9, 1.1, 1.0), M.shearing(0.1, 0, 0, 0, 0.05, 0),
+                 M.translation(0, 0.3, 0.2) * M.rotation_x(-0.2)]
+        for t in steps:            # five more transformed groups around it: six in all
+            outer = api.Group(t)
+            outer.add_child(g)
+            g = outer
+        floor = api.Plane(M.translation(0, -1.2, 0), Phong.default(), True)
+        lights = [api.PointLight(api.point(-6, 8, -8), Color.white()), api.PointLight(api.point(7, 5, -5), Color(0.3, 0.3, 0.3))]
+        return api.World([floor, g], lights)
+    assert abi.RT_MAX_XFORM_NEST >= 6
+    check(host, orc, make)
+
+
+def test_csg_of_thirteen_spheres(host, orc):
+    """A union whose left operand is a group of thirteen overlapping spheres: up to 28 intersections
+    of one ray with the shape, sorted and filtered at its end (csg.rs:80-107, 143-156)."""
+    def make(api):
+        M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+        mat = Phong(Solid(Color(0.3, 0.7, 0.4)), 0.1, 0.8, 0.5, 80.0, 0.1, 0.0, 1.0)
+        g = api.Group()
+        for k in range(13):
+            a = 2 * math.pi * k / 13
+            g.add_child(api.Sphere(M.translation(1.1 * math.cos(a), 1.0 + 0.25 * math.sin(3 * a), 1.1 * math.sin(a)) * M.scaling(0.6, 0.6, 0.6),
+                                   mat, True))
+        hub = api.Sphere(M.translation(0, 1, 0) * M.scaling(0.9, 0.9, 0.9), Phong(Solid(Color(0.8, 0.2, 0.2)), 0.1, 0.8, 0.3, 50.0, 0.0, 0.0, 1.0), True)
+        ring = api.CSG(api.UNION, g, hub)
+        bite = api.CSG(api.DIFFERENCE, ring, api.Cube(M.translation(0, 1.9, -1.0) * M.scaling(0.7, 0.7, 0.7), mat, True))
+        floor = api.Plane(M.identity(), Phong.default(), True)
+        lights = [api.PointLight(api.point(-6, 8, -8), Color.white())]
+        return api.World([floor, bite], lights)
+    check(host, orc, make, frm=(0, 4.5, -7))
+
+
+def test_six_nested_blended_and_gradient_patterns(host, orc):
+    def make(api):
+        M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+        p = api.Checker(Solid(Color(0.9, 0.9, 0.2)), Solid(Color(0.1, 0.2, 0.7)), M.scaling(0.4, 0.4, 0.4))
+        for k in range(6):  # six evaluating patterns inside one another
+            other = api.Striped(Solid(Color(0.2 + 0.1 * k, 0.5, 0.3)), Solid(Color(0.6, 0.1 * k, 0.4)), M.rotation_y(0.3 * k) * M.scaling(0.5, 0.5, 0.5))
+            if k % 2:
+                p = api.Gradient(p, other, M.translation(0.1 * k, 0, 0) * M.scaling(1.5, 1.5, 1.5))
+            else:
+                p = api.Blended(other, p, M.rotation_z(0.2 * k))
+        ball = api.Sphere(M.translation(0, 1, 0), Phong(p, 0.2, 0.8, 0.2, 50.0, 0.0, 0.0, 1.0), True)
+        floor = api.Plane(M.identity(), Phong(p, 0.2, 0.8, 0.0, 50.0, 0.0, 0.0, 1.0), True)
+        return api.World([floor, ball], [api.PointLight(api.point(-6, 8, -8), Color.white())])
+    assert abi.RT_MAX_PATTERN_NEST >= 6
+    check(host, orc, make)
