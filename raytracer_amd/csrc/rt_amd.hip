@@ -67,9 +67,10 @@ namespace {
 // collect their intersections per lane instead of competing for the nearest hit; the end record
 // sorts and filters them.
 enum { T_XFORM = 8, T_CULL = 9, T_CSG_BEGIN = 10, T_CSG_END = 11, T_HAS_INV = 0x100, T_CLOSED = 0x200,
-       T_OWN_XFORM = 0x400, T_LINE_ONLY = 0x800, T_CSG_OP_SHIFT = 12 };
+       T_OWN_XFORM = 0x400, T_LINE_ONLY = 0x800, T_CSG_OP_SHIFT = 12, T_DIAG = 0x4000 };
 struct alignas(16) TRec {
     int kind;    // low byte: RT_* type or T_XFORM; T_HAS_INV: p holds rows 0..2 of the inverse; T_CLOSED;
+                 // T_DIAG: that inverse is a scale and a translation (its six off-diagonal entries are zeros);
                  // T_OWN_XFORM: the record before this one is this node's T_XFORM record;
                  // T_LINE_ONLY (groups): hits below can lie outside the box, test the ray's line only
     int skip;    // first record after this node's subtree
@@ -180,10 +181,14 @@ DI V3 xnormal(P t, V3 n) {
 // Applies, outermost first, the inverse transforms of the non-identity groups that enclose a node
 // whose `ctx` link is `ctx` (Shape::intersect applied level by level, src/geometry/shape.rs:23-29,
 // and Shape::world_to_object, shape.rs:65-79).  Identity levels are exact no-ops and are skipped.
+// XF: the scene has transformed groups at all (without them no leaf has a transformed ancestor).
+template <bool XF>
 DI V3 to_object(const DevScene& S, const RT_CONST SRec* r, V3 p) {
+    if (XF) {
 #pragma unroll
-    for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
-        if (r->anc_xf[k] >= 0) p = xpoint(S.xforms[r->anc_xf[k]].inv, p);
+        for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
+            if (r->anc_xf[k] >= 0) p = xpoint(S.xforms[r->anc_xf[k]].inv, p);
+    }
     if (r->flags & S_HAS_XFORM) p = xpoint(r->inv, p);
     return p;
 }
@@ -402,6 +407,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     double coo, cym;   // |co|^2 scales the padding of T_CULL boxes; cym = largest |cy|
     double tpad;       // see prune_margin
     bool cfin;
+    bool plain;        // wave-uniform: every active lane's ray has finite components (see T_DIAG)
     auto ray_changed = [&]() {
         cy = reciprocal(cd);
         if (!XF) cn = mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z));
@@ -410,6 +416,10 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (!XF) cym = m;
         tpad = prune_margin(S.prune_base, coo, m);
         cfin = all_axes_finite(cd);
+        const double big = 1.7976931348623157e308;
+        const bool finite = fabs(co.x) <= big && fabs(co.y) <= big && fabs(co.z) <= big && fabs(cd.x) <= big &&
+                            fabs(cd.y) <= big && fabs(cd.z) <= big;
+        plain = wave_ballot(active && !finite) == 0ull;
     };
     ray_changed();
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
@@ -724,7 +734,14 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             continue;
         }
         V3 lo = co, ld = cd;
-        if (kind & T_HAS_INV) {  // Shape::intersect: world_ray.transform(inverse) (shape.rs:24-26, ray.rs:30-35)
+        if ((kind & T_DIAG) && plain) {
+            // The same products and sums with the terms left out that are exact zeros: 0 * finite is
+            // +-0, and x + (+-0) is x, except that an exact zero may come out with the other sign; no
+            // leaf test can tell (times that are +-0 do not count as hits, directions that are +-0 take
+            // the `* INFINITY` branches, squares and differences from +-1 lose the sign).
+            lo = mk(q[0] * co.x + q[3], q[5] * co.y + q[7], q[10] * co.z + q[11]);
+            ld = mk(q[0] * cd.x, q[5] * cd.y, q[10] * cd.z);
+        } else if (kind & T_HAS_INV) {  // Shape::intersect: world_ray.transform(inverse) (shape.rs:24-26, ray.rs:30-35)
             lo = xpoint(q, co);
             ld = xvec(q, cd);
         }
@@ -857,12 +874,21 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
 // the parent.  Identity levels skip the product but not the normalisation; once the magnitude is
 // exactly 1.0 further identity levels cannot change the vector, so the walk jumps to the next
 // enclosing non-identity group.
+template <bool XF>
 DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
     if (r->flags & S_HAS_XFORM) n = xnormal(r->inv_t, n);
     double m = magnitude(n);
     n = n / m;
     const int n_levels = r->n_levels;
     int level = 1;
+    if (!XF) {  // only identity ancestors: normalise until the length is exactly 1
+        while (level < n_levels && m != 1.0) {
+            m = magnitude(n);
+            n = n / m;
+            ++level;
+        }
+        return n;
+    }
 #pragma unroll
     for (int k = 0; k <= RT_MAX_XFORM_NEST; ++k) {
         const int xf = k < RT_MAX_XFORM_NEST ? r->anc_xf[k] : -1;
@@ -883,11 +909,12 @@ DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
 
 // Shape::normal_at (shape.rs:52-59) for the point where the ray (ro, rd) hits the leaf `sr`: the point
 // to object space, the leaf's local_normal_at, and the normal back to world space.
+template <bool XF>
 DI V3 normal_at(const DevScene& S, const RT_CONST SRec* sr, V3 ro, V3 rd, V3 point) {
     const int type = sr->type;
     const int sflags = sr->flags;
     const int data = sr->tri;
-    V3 lp = to_object(S, sr, point);
+    V3 lp = to_object<XF>(S, sr, point);
     V3 ln;
     switch (type) {
         case RT_SPHERE:  // sphere.rs:109-111
@@ -930,13 +957,15 @@ DI V3 normal_at(const DevScene& S, const RT_CONST SRec* sr, V3 ro, V3 rd, V3 poi
             // The hit's u and v (smooth_triangle.rs:101-129) are not carried through the
             // traversal: the same operations on the same ray give the same bits here.
             V3 lo = ro, ld = rd;
+            if (XF) {
 #pragma unroll
-            for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
-                if (sr->anc_xf[k] >= 0) {
-                    const RT_CONST double* m = S.xforms[sr->anc_xf[k]].inv;
-                    lo = xpoint(m, lo);
-                    ld = xvec(m, ld);
-                }
+                for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
+                    if (sr->anc_xf[k] >= 0) {
+                        const RT_CONST double* m = S.xforms[sr->anc_xf[k]].inv;
+                        lo = xpoint(m, lo);
+                        ld = xvec(m, ld);
+                    }
+            }
             if (sflags & S_HAS_XFORM) {
                 lo = xpoint(sr->inv, lo);
                 ld = xvec(sr->inv, ld);
@@ -956,7 +985,7 @@ DI V3 normal_at(const DevScene& S, const RT_CONST SRec* sr, V3 ro, V3 rd, V3 poi
             break;
         }
     }
-    return normal_to_world(S, sr, ln);
+    return normal_to_world<XF>(S, sr, ln);
 }
 
 // Improved-noise permutation (Ken Perlin, 2002), as used by patterns/perturbed.rs:8-34.
@@ -1211,7 +1240,7 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
         if (follow) {
             const RT_CONST SRec* sr = S.shade + h.node;
             const V3 point = ro + (rd * h.t);
-            V3 n = normal_at(S, sr, ro, rd, point);
+            V3 n = normal_at<XF>(S, sr, ro, rd, point);
             if (dot(n, -rd) < 0.0) n = -n;
             ro = point + (n * RT_EPS);
             rd = reflect(rd, n);
@@ -1428,7 +1457,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
             const int sflags = sr->flags;
             V3 point = ro + (rd * h.t);  // Ray::position (ray.rs:24-26)
             V3 eyev = -rd;
-            normalv = normal_at(S, sr, ro, rd, point);  // Shape::normal_at (shape.rs:52-59)
+            normalv = normal_at<XF>(S, sr, ro, rd, point);  // Shape::normal_at (shape.rs:52-59)
             if (dot(normalv, eyev) < 0.0) normalv = -normalv;
             over = point + (normalv * RT_EPS);
 
@@ -1491,7 +1520,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
             if (sflags & S_SOLID) {
                 colour = mk(sr->colour[0], sr->colour[1], sr->colour[2]);
             } else {
-                colour = pattern_eval(S, sr->pattern, to_object(S, sr, over));
+                colour = pattern_eval(S, sr->pattern, to_object<XF>(S, sr, over));
             }
         }
         const bool has_children = want_refl || want_refr;
@@ -2590,6 +2619,12 @@ struct RecordBuilder {
             if (n.xform >= 0) {
                 flags |= T_HAS_INV;
                 std::memcpy(r.p, d->xforms[n.xform].inv, sizeof r.p);
+                const double* m = d->xforms[n.xform].inv;
+                // not inside CSG shapes: their intersection lists are sorted by a total order that
+                // tells -0 from +0
+                static const bool diag_enabled = !(getenv("RT_DIAG") && atoi(getenv("RT_DIAG")) == 0);  // diagnostic switch
+                if (diag_enabled && !in_csg && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0)
+                    flags |= T_DIAG;
             }
         }
         r.kind = (n.type == RT_CSG ? (int)T_CSG_BEGIN : n.type) | flags;

@@ -1,5 +1,6 @@
 """The library's diagnostic switches must not change a pixel: every mechanism they turn off (cull
-boxes, sorted siblings, cost-ordered tiles) only decides what work is skipped or when it is done.
+boxes, sorted siblings, cost-ordered tiles, the short form of scale-and-translation transforms,
+strips and work sharing) only decides what work is skipped or when it is done.
 The library reads them once per process, so each setting renders in a child process."""
 import hashlib
 import os
@@ -27,7 +28,7 @@ for name, (W, H) in (("default", (1024, 576)), ("glass", (320, 200)), ("csg", (2
 
 def render_hashes(env_extra):
     env = dict(os.environ)
-    for k in ("RT_NO_CULL", "RT_REORDER", "RT_TILE_ORDER"):
+    for k in ("RT_NO_CULL", "RT_REORDER", "RT_TILE_ORDER", "RT_DIAG", "RT_SPLIT", "RT_PROBE"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
@@ -38,6 +39,7 @@ def render_hashes(env_extra):
 def test_switches_do_not_change_a_pixel():
     base = render_hashes({})
     assert len(base) == 5
-    for env in ({"RT_NO_CULL": "1"}, {"RT_REORDER": "0"}, {"RT_TILE_ORDER": "0"},
+    for env in ({"RT_NO_CULL": "1"}, {"RT_REORDER": "0"}, {"RT_TILE_ORDER": "0"}, {"RT_DIAG": "0"}, {"RT_SPLIT": "1"},
+                {"RT_SPLIT": "4", "RT_PROBE": "0"}, {"RT_SPLIT": "2", "RT_PROBE": "3"},
                 {"RT_NO_CULL": "1", "RT_REORDER": "0", "RT_TILE_ORDER": "0"}):
         assert render_hashes(env) == base, env
