@@ -2799,9 +2799,12 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
     bool share = false;
     if (job.tile_order && s->any_transparent && !s->any_csg) {
         static const int split_env = getenv("RT_SPLIT") ? atoi(getenv("RT_SPLIT")) : 0;
-        // measured on the default scene: 8,100 tiles 0.42 -> 0.26 ms with four strips, 32,400 tiles
-        // 0.47 -> 0.35 ms with two; at 129,600 tiles and beyond strips only add work
-        int split = split_env ? split_env : (tiles >= 65536 ? 1 : (tiles >= 16384 ? 2 : 4));
+        // measured on the default scene: 8,100 tiles 0.42 -> 0.25 ms with four strips, 32,400 tiles
+        // 0.47 -> 0.35 ms with two, 64,800 tiles (an eighth of 7680x4320) 0.47 -> 0.49 ms, and at 129,600
+        // tiles and beyond strips and sharing only add work (+13 % at 7680x4320).  Running the strips as
+        // a launch of their own beside a plain launch for the other tiles was tried and is worse at
+        // every size: the other tiles lose the sharing, which is most of the gain on small frames.
+        int split = split_env ? split_env : (tiles >= 49152 ? 1 : (tiles >= 16384 ? 2 : 4));
         if (split != 1 && split != 2 && split != 4) split = 1;
         if (split > 1) {
             const long long cap = tiles / 8 > 1024 ? tiles / 8 : 1024;  // beyond that many extra strips: whole tiles
