@@ -78,6 +78,8 @@ struct alignas(16) TRec {
     int node;    // index into the node table (what a hit reports)
     double r0, r1;  // cylinder / cone minimum, maximum
     double p[12];   // inverse rows | group bounds (6) | triangle p1, e1, e2 (9)
+                    // boxes (T_CULL, groups, CSG begin): p[6..8] = the (low, high) planes per axis as float pairs,
+                    // p[9] = two float factors of the margin (see slabs_f32 and fill_box_f32)
 };
 static_assert(sizeof(TRec) == 128, "traversal record must be 128 bytes");
 
@@ -111,9 +113,8 @@ struct DevScene {
     const RT_CONST rt_light* lights;
     int n_lights;
     int all_cast_shadow;
-    int finite_bounds;  // every group box is finite (no plane inside a group)
-    double prune_base;  // 1 + the largest |coordinate| of any group box; infinite when a box is
-                        // (scales the margin for pruning subtrees by their box times)
+    float prune_f32;    // 2.02e-9 * (1 + the largest |coordinate| of any group box), rounded up; infinite when
+                        // a box is (no subtree is then pruned by its box times): see slabs_f32
 };
 
 struct DevJob {
@@ -271,27 +272,70 @@ DI double rcp_exact(double d) {
 DI double reciprocal1(double d) { return fabs(d) >= RT_EPS ? rcp_exact(d) : __builtin_nan(""); }
 DI V3 reciprocal(V3 d) { return mk(reciprocal1(d.x), reciprocal1(d.y), reciprocal1(d.z)); }
 
-// Slack, in ray-time units, for pruning subtrees by their box times: a child's computed time can
-// differ from the box times of its group by rounding.  Times are at most about
-// (|origin| + extent) / |direction| and carry a few ulps of that; cancellation in the quadratics
-// adds a term that grows with |origin|^2.  base = 1 + extent of the group boxes.
-DI double largest_abs(V3 v) { return fmax(fmax(fabs(v.x), fabs(v.y)), fabs(v.z)); }  // NaN components are ignored
-DI double prune_margin(double base, double origin_sq, double largest_rcp_dir) {
-    double m = (1e-9 * (base + origin_sq)) * largest_rcp_dir;
-    return (m == m) ? m : INFINITY;  // no finite reciprocal at all: never prune
+// ---- box tests in single precision ------------------------------------------------------------
+// Whether a ray can reach a box only decides what the walk skips, never a value that is stored, so
+// the decision may come from approximate slab times as long as their error is bounded and every
+// comparison leaves that much room.  Per axis t = plane * y + n with y = 1 / d and n = -o * y; in f32,
+// with y from the hardware reciprocal (1 ulp) of the rounded d, each time differs from the real
+// quotient by less than 6 u |y| (|plane| + |o|), u = 2^-24: the roundings of plane, d, o, the
+// reciprocal, the product o * y and the fused multiply-add (the reference's own f64 roundings are
+// nine orders of magnitude below that).  The margin uses 16 u:
+//     G = 2 * 16 u * ym * (E + so)  +  pad  +  1e-30
+// ym = largest |y| over the axes that count, E = largest |plane| of the box, so = |ox| + |oy| + |oz|;
+// pad is the allowance the f64 tests had: for T_CULL boxes (r0 + r1 |o|^2) ym (a leaf's own
+// quadratic can report a hit slightly outside its box: see fill_cull), for group boxes
+// 2e-9 (base + |o|^2) ym (a child's time and its group's box times round differently); 1e-30
+// covers values that f32 flushes to zero.  The walk takes these shortcuts only for rays whose
+// components are all below 1e15 in magnitude (`tame`; directions that count are at least RT_EPS), so
+// that nothing overflows or leaves the normal range of f32; other rays get an infinite margin, which
+// decides nothing.
+// Axes the reference treats as parallel to the slab (|d| < RT_EPS, bounding_box.rs:107-113) carry
+// NaN and drop out of min / max: the box test then ignores that axis, which can only keep more.
+// A group's bounds test must agree with the reference's (group.rs:133-154) exactly; lanes whose
+// tmin and tmax are closer than the margin, or that have a parallel axis, repeat it in f64.
+typedef float f2 __attribute__((ext_vector_type(2)));
+constexpr float BOX_F32_2C = 1.9073486328125e-6f;  // 2 * 16 u = 2^-19
+// (planes.x * y + n, planes.y * y + n) with (y, n) = yn: one packed instruction, the record's planes
+// straight from scalar registers.  The min / max below are written as instructions too: the
+// compiler cannot see that these values are never signalling NaNs and would canonicalise each one.
+DI f2 slab_pair(double planes, f2 yn) {
+    f2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(t) : "s"(planes), "v"(yn));
+    return t;
 }
-// Approximate slab times as one FMA each: plane * (1/d) + (-origin/d), with y = 1/d correctly
-// rounded and n = -(origin * y) rounded once.  Each differs from the reference's quotient
-// (plane - origin) / d by at most about 3 eps (|plane| + |origin|) |y|.  Good enough to cull, and to
-// decide tmin > tmax unless the two are that close.  NaN (parallel) axes drop out of min / max.
-DI void slabs_near(V3 y, V3 n, double x0, double y0, double z0, double x1, double y1, double z1, double& tmin,
-                   double& tmax) {
-    double ax = __builtin_fma(x0, y.x, n.x), bx = __builtin_fma(x1, y.x, n.x);
-    double ay = __builtin_fma(y0, y.y, n.y), by = __builtin_fma(y1, y.y, n.y);
-    double az = __builtin_fma(z0, y.z, n.z), bz = __builtin_fma(z1, y.z, n.z);
-    tmin = fmax(fmax(fmin(ax, bx), fmin(ay, by)), fmin(az, bz));
-    tmax = fmin(fmin(fmax(ax, bx), fmax(ay, by)), fmax(az, bz));
+DI float min_f32(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
 }
+DI float max_f32(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+DI float max3_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+DI float min3_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+DI float max3_abs_f32(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// px, py, pz: the box's (low, high) planes per axis as two floats in one 8-byte slot of the record
+DI void slabs_f32(double px, double py, double pz, f2 ynx, f2 yny, f2 ynz, float& tmin, float& tmax) {
+    const f2 tx = slab_pair(px, ynx), ty = slab_pair(py, yny), tz = slab_pair(pz, ynz);
+    tmin = max3_f32(min_f32(tx.x, tx.y), min_f32(ty.x, ty.y), min_f32(tz.x, tz.y));
+    tmax = min3_f32(max_f32(tx.x, tx.y), max_f32(ty.x, ty.y), max_f32(tz.x, tz.y));
+}
+// An f32 that is not below the positive f64 x (or within 1e-38 of it when x is that small).
+DI float up_f32(double x) { return (float)x * 1.00000012f; }
 
 // Per-leaf accumulator: nearest positive time (Intersection::hit, intersection.rs:32-41) and,
 // for the n1/n2 bookkeeping, the parity and the latest of the leaf's non-positive times.
@@ -402,24 +446,37 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     int i = 0;
     int cur_ctx = -1;
     V3 co = wo, cd = wd;  // the ray in the space of the transformed group `cur_ctx`
-    V3 cy, cn;         // exact reciprocals of cd (NaN where the reference treats the axis as parallel), and -co * cy
-                       // (with transformed groups cn and cym are formed at each use instead: registers are scarcer there)
-    double coo, cym;   // |co|^2 scales the padding of T_CULL boxes; cym = largest |cy|
-    double tpad;       // see prune_margin
-    bool cfin;
-    bool plain;        // wave-uniform: every active lane's ray has finite components (see T_DIAG)
+    // The ray as the single-precision box tests see it (see slabs_f32): per axis (1 / d, -o / d), the
+    // largest |1 / d|, a bound on |o|^2 times that, and the parts of the margins that do not depend
+    // on the box.  hlim: no time beyond it counts (the light's distance for a shadow ray, then the
+    // nearest hit so far; for the container pass only times <= 0 count).
+    f2 ynx, yny, ynz;
+    float ym, osq_ym, c_cull, c_group;
+    float hlim = TRACK ? 0.0f : (MODE == MODE_SHADOW ? up_f32(limit) : INFINITY);
+    bool cfin;   // no axis of this lane's ray counts as parallel to a slab
+    bool plain;  // wave-uniform: every active lane's ray is tame, in particular finite (see T_DIAG)
     auto ray_changed = [&]() {
-        cy = reciprocal(cd);
-        if (!XF) cn = mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z));
-        coo = dot(co, co);
-        const double m = largest_abs(cy);
-        if (!XF) cym = m;
-        tpad = prune_margin(S.prune_base, coo, m);
-        cfin = all_axes_finite(cd);
-        const double big = 1.7976931348623157e308;
-        const bool finite = fabs(co.x) <= big && fabs(co.y) <= big && fabs(co.z) <= big && fabs(cd.x) <= big &&
-                            fabs(cd.y) <= big && fabs(cd.z) <= big;
-        plain = wave_ballot(active && !finite) == 0ull;
+        const bool fx = fabs(cd.x) >= RT_EPS, fy = fabs(cd.y) >= RT_EPS, fz = fabs(cd.z) >= RT_EPS;
+        cfin = fx && fy && fz;
+        const float dx = (float)cd.x, dy = (float)cd.y, dz = (float)cd.z;
+        const float ox = (float)co.x, oy = (float)co.y, oz = (float)co.z;
+        const float yx = fx ? __builtin_amdgcn_rcpf(dx) : __builtin_nanf("");
+        const float yy = fy ? __builtin_amdgcn_rcpf(dy) : __builtin_nanf("");
+        const float yz = fz ? __builtin_amdgcn_rcpf(dz) : __builtin_nanf("");
+        ynx = (f2){yx, -(ox * yx)};
+        yny = (f2){yy, -(oy * yy)};
+        ynz = (f2){yz, -(oz * yz)};
+        ym = max3_abs_f32(yx, yy, yz);
+        const float so = (fabsf(ox) + fabsf(oy)) + fabsf(oz);
+        const float sd = (fabsf(dx) + fabsf(dy)) + fabsf(dz);
+        const bool tame = (so + sd) <= 1e15f;  // false for NaN and infinite components too
+        const float osq = so * so;             // >= |o|^2
+        const float cc = __builtin_fmaf(ym * BOX_F32_2C, so, 1e-30f);
+        const float cg = __builtin_fmaf(ym, __builtin_fmaf(2.02e-9f, osq, S.prune_f32), cc);
+        c_cull = tame ? cc : INFINITY;
+        c_group = tame ? cg : INFINITY;
+        osq_ym = osq * ym;
+        plain = wave_ballot(active && !tame) == 0ull;
     };
     ray_changed();
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
@@ -457,6 +514,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             const bool better = acc.best != 0.0 && (h.node < 0 || acc.best < h.t || (acc.best == h.t && acc_node < h.node));
             h.t = better ? acc.best : h.t;
             h.node = better ? acc_node : h.node;
+            if (!early) hlim = better ? min_f32(hlim, up_f32(acc.best)) : hlim;  // with `early` the lane is decided below
         } else {
             h.par = acc_node == h.node ? acc.par : h.par;  // parity of the hit leaf's own earlier times
             const bool odd = acc.par != 0;
@@ -523,23 +581,16 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         }
 #endif
         if (CULL && type == T_CULL) {
-            // Box p[0..5] grown by r0 + r1 * |origin|^2: r0 covers the rounding of this test, the
-            // second term the rounding of the leaf's own quadratic for far-away origins (its
-            // discriminant loses about eps * |origin|^2, which can turn a near miss into a hit).
-            // The growth is applied to the times: moving a plane by pad moves its time by at most
-            // pad * cym.  NaN times (parallel axes) leave their axis unconstrained.
-            const double padt = __builtin_fma(r1, coo, r0) * (XF ? largest_abs(cy) : cym);
-            double tmin, tmax;
-            slabs_near(cy, XF ? mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z)) : cn, q[0], q[1], q[2], q[3], q[4], q[5],
-                       tmin, tmax);
-            tmin -= padt;
-            tmax += padt;
-            bool keep = !(tmin > tmax);
+            // Padded box in front of a leaf or a run of siblings, tested in single precision (see
+            // slabs_f32): p[6..8] hold the planes as floats, p[9] the margin's two box-dependent factors.
+            float tmin, tmax;
+            slabs_f32(q[6], q[7], q[8], ynx, yny, ynz, tmin, tmax);
+            const f2 kk = __builtin_bit_cast(f2, q[9]);
+            const float G = __builtin_fmaf(kk.y, osq_ym, __builtin_fmaf(kk.x, ym, c_cull));
+            bool keep = !((tmin - tmax) > G);
             if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
-                if (!TRACK) keep = keep && !(tmax < 0.0);                     // only positive times count
-                if (MODE == MODE_SHADOW) keep = keep && !(tmin > limit);     // beyond the light
-                if (!TRACK) keep = keep && !(h.node >= 0 && tmin > h.t);     // behind the nearest hit so far
-                if (TRACK) keep = keep && !(tmin > 0.0);                      // only times <= 0 count
+                if (!TRACK) keep = keep && !(tmax < -G);  // only positive times count
+                keep = keep && !((tmin - G) > hlim);      // beyond the light or the nearest hit so far; container pass: > 0
             }
             keep = keep && act;
             if (act && !keep) skip_until = skip;
@@ -699,30 +750,27 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (type == RT_GROUP || (CSGM && type == T_CSG_BEGIN)) {
             // Group::local_intersect (group.rs:133-154) and CSG::local_intersect (csg.rs:145):
             // bounds test in the shape's own space.
-            double tmin, tmax;
-            if (S.finite_bounds && wave_ballot(act && !cfin) == 0ull) {
-                // The approximate times decide almost every lane; the exact quotients are only
-                // computed when some lane's tmin and tmax are closer than the approximation is
-                // good for: both carry up to 3 eps (extent + |origin|) cym, and
-                // 6 eps (e + o) <= 4e-15 (1 + e + o^2) = 4e-6 tpad / cym for all e, o >= 0.
-                slabs_near(cy, XF ? mk(-(co.x * cy.x), -(co.y * cy.y), -(co.z * cy.z)) : cn, q[0], q[1], q[2], q[3], q[4],
-                           q[5], tmin, tmax);
-                const bool close = !(fabs(tmax - tmin) > 4e-6 * tpad);
-                if (wave_ballot(act && close) != 0ull)
-                    slabs_fast(co, cd, cy, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
-            } else {
-                slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], tmin, tmax);
+            // Single precision decides every lane whose tmin and tmax are further apart than the
+            // margin; the others (and lanes with an axis that counts as parallel, which the f32 test
+            // ignores but the reference does not) repeat the test in f64 exactly as the reference does.
+            float tmin, tmax;
+            slabs_f32(q[6], q[7], q[8], ynx, yny, ynz, tmin, tmax);
+            const float G = __builtin_fmaf(__builtin_bit_cast(f2, q[9]).x, ym, c_group);
+            const float gap = tmin - tmax;
+            bool miss = gap > G;
+            const bool unsure = act && (!(miss || gap < -G) || !cfin);
+            if (wave_ballot(unsure) != 0ull) {
+                double e0, e1;
+                slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], e0, e1);
+                miss = unsure ? (e0 > e1) : miss;
             }
-            bool inside = act && !(tmin > tmax);
+            bool inside = act && !miss;
             // The reference enters every group whose box the ray's LINE meets.  Subtrees that can
             // only yield times that do not count are skipped: behind the origin (unless the n1/n2
             // bookkeeping needs the times <= 0), beyond the light, beyond the nearest hit so far.
-            // tpad absorbs the rounding between a child's time and its group's box times.
             if ((!CSGM || csg_depth == 0) && !(kind & T_LINE_ONLY)) {  // inside a CSG shape its filter needs every intersection
-                if (!TRACK) inside = inside && !(tmax < -tpad);
-                if (MODE == MODE_SHADOW) inside = inside && !(tmin > limit + tpad);
-                if (!TRACK) inside = inside && !(h.node >= 0 && tmin > h.t + tpad);
-                if (TRACK) inside = inside && !(tmin > tpad);
+                if (!TRACK) inside = inside && !(tmax < -G);
+                inside = inside && !((tmin - G) > hlim);
             }
             if (act && !inside) skip_until = skip;
             const bool enter = wave_ballot(inside) != 0ull;
@@ -2262,6 +2310,31 @@ bool affine_forward(const double inv[12], double fwd[12]) {
     return true;
 }
 
+// Smallest float that is not below v (v >= 0).
+float round_up_f32(double v) {
+    float f = (float)v;
+    if ((double)f < v) f = std::nextafterf(f, INFINITY);
+    return f;
+}
+// The single-precision image of a box for the device's slabs_f32: planes rounded to nearest, and the
+// two factors of the margin that depend on the box: k0 = 2 * 16 u * (largest |plane|) + pad0 (times the
+// largest |1 / d| of the ray) and k1 = pad1 (times a bound on |o|^2 / |d|).  An infinite box gets an
+// infinite k0: nothing is then decided in single precision.
+void fill_box_f32(TRec& r, const double bmin[3], const double bmax[3], double pad0, double pad1) {
+    float planes[6], kk[2];
+    double reach = 0.0;
+    for (int k = 0; k < 3; ++k) {
+        planes[2 * k] = (float)bmin[k];
+        planes[2 * k + 1] = (float)bmax[k];
+        reach = std::fmax(reach, std::fmax(std::fabs(bmin[k]), std::fabs(bmax[k])));
+    }
+    const double k0 = (1.9073486328125e-6 * reach + pad0) * (1.0 + 1e-6);
+    kk[0] = std::isfinite(k0) && reach <= 1e15 ? round_up_f32(k0) : INFINITY;  // NaN planes too
+    kk[1] = round_up_f32(pad1 * (1.0 + 1e-6));
+    std::memcpy(&r.p[6], planes, sizeof planes);
+    std::memcpy(&r.p[9], kk, sizeof kk);
+}
+
 // Fills a T_CULL record for the box [bmin, bmax].  far_term: see NodeBox::far.
 bool fill_cull(const double bmin[3], const double bmax[3], double far_term, TRec& out) {
     double size = 0.0, reach = 0.0;
@@ -2278,6 +2351,7 @@ bool fill_cull(const double bmin[3], const double bmax[3], double far_term, TRec
         out.p[k] = bmin[k];
         out.p[3 + k] = bmax[k];
     }
+    fill_box_f32(out, bmin, bmax, out.r0, out.r1);
     return true;
 }
 
@@ -2634,6 +2708,7 @@ struct RecordBuilder {
             const double* mx = d->aabbs[n.data].max;
             std::memcpy(r.p, mn, 3 * sizeof(double));
             std::memcpy(r.p + 3, mx, 3 * sizeof(double));
+            fill_box_f32(r, mn, mx, 0.0, 0.0);
             if (cone_below[i]) {
                 r.kind |= T_LINE_ONLY;
             } else {
@@ -2930,6 +3005,14 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     int rc = validate(d, all_cast, any_transparent);
     if (rc != RT_OK) return rc;
     const double t_validated = rtdl::now_ms();
+    if (getenv("RT_DUMP_RECORDS")) {  // diagnostic: the traversal records as text, before any device is needed
+        const std::vector<TRec> recs = build_records(d);
+        for (size_t k = 0; k < recs.size(); ++k) {
+            const TRec& r = recs[k];
+            fprintf(stderr, "rec %3zu type %3d flags %#6x node %3d skip %3d ctx %3d  [%g %g %g | %g %g %g] r0 %g r1 %g\n", k, r.kind & 0xff,
+                    r.kind & ~0xff, r.node, r.skip, r.ctx, r.p[0], r.p[1], r.p[2], r.p[3], r.p[4], r.p[5], r.r0, r.r1);
+        }
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(RT_ERR_NO_DEVICE, "no HIP device is visible");
@@ -2982,15 +3065,15 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if ((rc = upload(s, d->lights, d->n_lights, &s->dev.lights)) != RT_OK) return cleanup(rc);
     s->dev.n_lights = d->n_lights;
     s->dev.all_cast_shadow = all_cast ? 1 : 0;
-    s->dev.finite_bounds = 1;
+    bool finite_bounds = true;
     double extent = 0.0;
     for (int i = 0; i < d->n_aabbs; ++i)
         for (int k = 0; k < 3; ++k)
         {
-            if (!std::isfinite(d->aabbs[i].min[k]) || !std::isfinite(d->aabbs[i].max[k])) s->dev.finite_bounds = 0;
+            if (!std::isfinite(d->aabbs[i].min[k]) || !std::isfinite(d->aabbs[i].max[k])) finite_bounds = false;
             extent = std::fmax(extent, std::fmax(std::fabs(d->aabbs[i].min[k]), std::fabs(d->aabbs[i].max[k])));
         }
-    s->dev.prune_base = s->dev.finite_bounds ? 1.0 + extent : INFINITY;
+    s->dev.prune_f32 = finite_bounds ? round_up_f32(2.02e-9 * (1.0 + extent)) : INFINITY;
     void* p = nullptr;
     if (hipMalloc(&p, 2 * COUNTER_SET_WORDS * sizeof(unsigned long long)) != hipSuccess)
         return cleanup(fail(RT_ERR_HIP, "hipMalloc(counters) failed"));
