@@ -115,6 +115,12 @@ struct DevScene {
     int all_cast_shadow;
     float prune_f32;    // 2.02e-9 * (1 + the largest |coordinate| of any group box), rounded up; infinite when
                         // a box is (no subtree is then pruned by its box times): see slabs_f32
+    // Cubes (see the note at slabs_f32).  Scenes whose cubes are all axis-aligned in every space their
+    // boxes are tested in: cube_kappa = 0 and rays with a direction component below RT_EPS * stretch
+    // (ym above ym_limit) are not tame.  Other scenes: cube_kappa = 2 * 1.4143e-5 * stretch pads the boxes
+    // per ray, and rays with ymin above ymin_limit (cube_kappa * ymin > 1/2) are not tame.
+    float cube_kappa, ym_limit, ymin_limit;
+    float extent_f32;   // largest |plane| of any box record
 };
 
 struct DevJob {
@@ -293,14 +299,35 @@ DI V3 reciprocal(V3 d) { return mk(reciprocal1(d.x), reciprocal1(d.y), reciproca
 // NaN and drop out of min / max: the box test then ignores that axis, which can only keep more.
 // A group's bounds test must agree with the reference's (group.rs:133-154) exactly; lanes whose
 // tmin and tmax are closer than the margin, or that have a parallel axis, repeat it in f64.
+// Cubes: for an axis whose object-space direction component is below RT_EPS the reference only asks
+// whether the ORIGIN lies between the two faces (cube.rs:47-69), so the hit it reports at time t can
+// lie outside the cube by up to RT_EPS |t| along that axis: at most sqrt(2) RT_EPS |t| in object
+// space (with three such axes the times are infinite), kappa |t| in the space of a box around the
+// cube, kappa = 1.4143e-5 * stretch.  Two ways to stay on the safe side, chosen per scene:
+//   * every cube is axis-aligned in every space its boxes are tested in (the chain of transforms
+//     above it only scales and translates): the branch is only taken by rays with a direction
+//     component below RT_EPS * stretch in that space, and those are simply not tame;
+//   * otherwise the boxes are grown per ray by rho >= kappa |t|: a hit at time t lies within
+//     E + rho + so of the origin along every axis, so |t| <= (E + so + rho) ymin (ymin = smallest |y|)
+//     and rho = 2 kappa ymin (E + so) does while kappa ymin <= 1/2 (E: the largest |plane| of any box
+//     of the scene).  Growing a box by rho is n -+ rho y in the two slab times of an axis, which costs
+//     nothing per box.  Group bounds tests see the grown box too: what it misses the group's own box
+//     misses, and a lane only counts as inside without the f64 test when tmax - tmin exceeds the
+//     margin by 4 rho ym more.
 typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr float BOX_F32_2C = 1.9073486328125e-6f;  // 2 * 16 u = 2^-19
-// (planes.x * y + n, planes.y * y + n) with (y, n) = yn: one packed instruction, the record's planes
-// straight from scalar registers.  The min / max below are written as instructions too: the
-// compiler cannot see that these values are never signalling NaNs and would canonicalise each one.
-DI f2 slab_pair(double planes, f2 yn) {
+// (planes.x * y + n.x, planes.y * y + n.y), y = the low (slab_lo) or high (slab_hi) half of yy: one
+// packed instruction, the record's planes straight from scalar registers.  The min / max below are
+// written as instructions too: the compiler cannot see that these values are never signalling NaNs
+// and would canonicalise each one.
+DI f2 slab_lo(double planes, f2 yy, f2 n) {
     f2 t;
-    asm("v_pk_fma_f32 %0, %1, %2, %2 op_sel:[0,0,1] op_sel_hi:[1,0,1]" : "=v"(t) : "s"(planes), "v"(yn));
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "s"(planes), "v"(yy), "v"(n));
+    return t;
+}
+DI f2 slab_hi(double planes, f2 yy, f2 n) {
+    f2 t;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(t) : "s"(planes), "v"(yy), "v"(n));
     return t;
 }
 DI float min_f32(float a, float b) {
@@ -323,14 +350,21 @@ DI float min3_f32(float a, float b, float c) {
     asm("v_min3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+DI float min3_abs_f32(float a, float b, float c) {
+    float r;
+    asm("v_min3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 DI float max3_abs_f32(float a, float b, float c) {
     float r;
     asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-// px, py, pz: the box's (low, high) planes per axis as two floats in one 8-byte slot of the record
-DI void slabs_f32(double px, double py, double pz, f2 ynx, f2 yny, f2 ynz, float& tmin, float& tmax) {
-    const f2 tx = slab_pair(px, ynx), ty = slab_pair(py, yny), tz = slab_pair(pz, ynz);
+// px, py, pz: the box's (low, high) planes per axis as two floats in one 8-byte slot of the record.
+// yxy = (1/dx, 1/dy), yz.x = 1/dz; nx, ny, nz: -o/d for the low and for the high plane (they differ by
+// the per-ray growth of the boxes, see the note on cubes).
+DI void slabs_f32(double px, double py, double pz, f2 yxy, f2 yz, f2 nx, f2 ny, f2 nz, float& tmin, float& tmax) {
+    const f2 tx = slab_lo(px, yxy, nx), ty = slab_hi(py, yxy, ny), tz = slab_lo(pz, yz, nz);
     tmin = max3_f32(min_f32(tx.x, tx.y), min_f32(ty.x, ty.y), min_f32(tz.x, tz.y));
     tmax = min3_f32(max_f32(tx.x, tx.y), max_f32(ty.x, ty.y), max_f32(tz.x, tz.y));
 }
@@ -450,11 +484,11 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     // largest |1 / d|, a bound on |o|^2 times that, and the parts of the margins that do not depend
     // on the box.  hlim: no time beyond it counts (the light's distance for a shadow ray, then the
     // nearest hit so far; for the container pass only times <= 0 count).
-    f2 ynx, yny, ynz;
-    float ym, osq_ym, c_cull, c_group;
+    f2 yxy, yz, nx, ny, nz;
+    float ym, osq_ym, c_cull, c_group, grow4;
     float hlim = TRACK ? 0.0f : (MODE == MODE_SHADOW ? up_f32(limit) : INFINITY);
     bool cfin;   // no axis of this lane's ray counts as parallel to a slab
-    bool plain;  // wave-uniform: every active lane's ray is tame, in particular finite (see T_DIAG)
+    bool plain;  // wave-uniform: every active lane's ray has finite components below 1e15 (see T_DIAG)
     auto ray_changed = [&]() {
         const bool fx = fabs(cd.x) >= RT_EPS, fy = fabs(cd.y) >= RT_EPS, fz = fabs(cd.z) >= RT_EPS;
         cfin = fx && fy && fz;
@@ -462,21 +496,37 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         const float ox = (float)co.x, oy = (float)co.y, oz = (float)co.z;
         const float yx = fx ? __builtin_amdgcn_rcpf(dx) : __builtin_nanf("");
         const float yy = fy ? __builtin_amdgcn_rcpf(dy) : __builtin_nanf("");
-        const float yz = fz ? __builtin_amdgcn_rcpf(dz) : __builtin_nanf("");
-        ynx = (f2){yx, -(ox * yx)};
-        yny = (f2){yy, -(oy * yy)};
-        ynz = (f2){yz, -(oz * yz)};
-        ym = max3_abs_f32(yx, yy, yz);
+        const float yzz = fz ? __builtin_amdgcn_rcpf(dz) : __builtin_nanf("");
+        ym = max3_abs_f32(yx, yy, yzz);
         const float so = (fabsf(ox) + fabsf(oy)) + fabsf(oz);
         const float sd = (fabsf(dx) + fabsf(dy)) + fabsf(dz);
-        const bool tame = (so + sd) <= 1e15f;  // false for NaN and infinite components too
+        const bool bounded = (so + sd) <= 1e15f;  // false for NaN and infinite components too
+        // per-ray growth of the boxes (scenes with cubes that are not axis-aligned, else zero)
+        const float mx = -(ox * yx), my = -(oy * yy), mz = -(oz * yzz);
+        yxy = (f2){yx, yy};
+        yz = (f2){yzz, 0.0f};
+        bool tame = bounded && ym <= S.ym_limit;
+        if (S.cube_kappa != 0.0f) {  // scenes with cubes that are not axis-aligned
+            const float ymin = min3_abs_f32(yx, yy, yzz);
+            const float rho = (S.cube_kappa * ymin) * (S.extent_f32 + so);
+            tame = tame && ymin <= S.ymin_limit;
+            nx = (f2){__builtin_fmaf(-rho, yx, mx), __builtin_fmaf(rho, yx, mx)};
+            ny = (f2){__builtin_fmaf(-rho, yy, my), __builtin_fmaf(rho, yy, my)};
+            nz = (f2){__builtin_fmaf(-rho, yzz, mz), __builtin_fmaf(rho, yzz, mz)};
+            grow4 = (4.0f * rho) * ym;
+        } else {
+            nx = (f2){mx, mx};
+            ny = (f2){my, my};
+            nz = (f2){mz, mz};
+            grow4 = 0.0f;
+        }
         const float osq = so * so;             // >= |o|^2
         const float cc = __builtin_fmaf(ym * BOX_F32_2C, so, 1e-30f);
         const float cg = __builtin_fmaf(ym, __builtin_fmaf(2.02e-9f, osq, S.prune_f32), cc);
         c_cull = tame ? cc : INFINITY;
         c_group = tame ? cg : INFINITY;
         osq_ym = osq * ym;
-        plain = wave_ballot(active && !tame) == 0ull;
+        plain = wave_ballot(active && !bounded) == 0ull;
     };
     ray_changed();
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
@@ -584,17 +634,26 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // Padded box in front of a leaf or a run of siblings, tested in single precision (see
             // slabs_f32): p[6..8] hold the planes as floats, p[9] the margin's two box-dependent factors.
             float tmin, tmax;
-            slabs_f32(q[6], q[7], q[8], ynx, yny, ynz, tmin, tmax);
+            slabs_f32(q[6], q[7], q[8], yxy, yz, nx, ny, nz, tmin, tmax);
             const f2 kk = __builtin_bit_cast(f2, q[9]);
             const float G = __builtin_fmaf(kk.y, osq_ym, __builtin_fmaf(kk.x, ym, c_cull));
-            bool keep = !((tmin - tmax) > G);
+            // (lane masks of the single comparisons, combined as scalars: a ballot of the combined
+            // condition would go through a vector register)
+            const bool c_miss = (tmin - tmax) > G;
+            bool keep = !c_miss;
+            unsigned long long drop = wave_ballot(c_miss);
             if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
-                if (!TRACK) keep = keep && !(tmax < -G);  // only positive times count
-                keep = keep && !((tmin - G) > hlim);      // beyond the light or the nearest hit so far; container pass: > 0
+                if (!TRACK) {
+                    const bool c_behind = tmax < -G;  // only positive times count
+                    keep = keep && !c_behind;
+                    drop |= wave_ballot(c_behind);
+                }
+                const bool c_beyond = (tmin - G) > hlim;  // beyond the light or the nearest hit so far; container pass: > 0
+                keep = keep && !c_beyond;
+                drop |= wave_ballot(c_beyond);
             }
-            keep = keep && act;
             if (act && !keep) skip_until = skip;
-            i = (wave_ballot(keep) == 0ull) ? skip : i + 1;
+            i = ((wave_ballot(act) & ~drop) == 0ull) ? skip : i + 1;
             continue;
         }
         if (CSGM && type == T_CSG_END) {
@@ -754,11 +813,11 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // margin; the others (and lanes with an axis that counts as parallel, which the f32 test
             // ignores but the reference does not) repeat the test in f64 exactly as the reference does.
             float tmin, tmax;
-            slabs_f32(q[6], q[7], q[8], ynx, yny, ynz, tmin, tmax);
+            slabs_f32(q[6], q[7], q[8], yxy, yz, nx, ny, nz, tmin, tmax);
             const float G = __builtin_fmaf(__builtin_bit_cast(f2, q[9]).x, ym, c_group);
             const float gap = tmin - tmax;
             bool miss = gap > G;
-            const bool unsure = act && (!(miss || gap < -G) || !cfin);
+            const bool unsure = act && (!(miss || (gap + grow4) < -G) || !cfin);
             if (wave_ballot(unsure) != 0ull) {
                 double e0, e1;
                 slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], e0, e1);
@@ -1586,8 +1645,14 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         if (shade) {
             const RT_CONST SRec* q = sr;
             asm volatile("" : "+v"(q));
-            no_direct = q->kd == 0.0 && q->ks == 0.0 && fabs(colour.x) < 1e100 && fabs(colour.y) < 1e100 &&
-                        fabs(colour.z) < 1e100;
+            // A zero specular coefficient makes the specular term an exact zero only while the power is
+            // finite (0 * inf is NaN): shininess in [0, 400] and a base of at most 5.4 keep it so.
+            // |reflectv . eyev| <= 3 |eyev| for unit light and normal vectors: with the direction's 1-norm at
+            // most 1.8 the base stays below 5.4.
+            const double shin = q->shin;
+            no_direct = q->kd == 0.0 && q->ks == 0.0 && shin >= 0.0 && shin <= 400.0 &&
+                        (fabs(rd.x) + fabs(rd.y)) + fabs(rd.z) <= 1.8 && fabs(colour.x) < 1e100 &&
+                        fabs(colour.y) < 1e100 && fabs(colour.z) < 1e100;
         }
         V3 acc = mk(0.0, 0.0, 0.0);
         for (int l = 0; l < L; ++l) {
@@ -1656,9 +1721,10 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                         V3 rv = reflect(-lightv, normalv);
                         double rde = dot(rv, -rd);
                         if (!(rde <= 0.0)) {
-                            // a zero specular coefficient makes the term an exact zero; skip pow
-                            const double ks = sr->ks;
-                            double factor = (ks == 0.0) ? 1.0 : pow(rde, sr->shin);
+                            // a zero specular coefficient makes the term an exact zero while the power is
+                            // finite (see no_direct); skip pow then
+                            const double ks = sr->ks, shin = sr->shin;
+                            double factor = (ks == 0.0 && shin >= 0.0 && shin <= 400.0 && rde <= 5.4) ? 1.0 : pow(rde, shin);
                             specular = lint * ks * factor;
                         }
                     }
@@ -2366,7 +2432,12 @@ struct NodeBox {
     // orders of magnitude over eps.  (The triangle test has no such cancellation; the same padding
     // is simply generous for it.)
     double far;
+    // Largest stretch from the object space of a cube at or below this node to the parent's space (0
+    // without cubes): a cube's reported hit can lie outside the cube by RT_EPS |t| per axis in object
+    // space (cube.rs:47-69 treats small direction components as parallel), this much further here.
+    double drift;
     bool ok;  // false: unbounded, or a transform too degenerate to bound
+    bool cubes_aligned;  // every cube at or below this node keeps its axes parallel to the parent's axes
 };
 
 // Boxes of all nodes, and which nodes are or contain a cone.
@@ -2375,6 +2446,8 @@ void node_boxes(const rt_scene_desc* d, std::vector<NodeBox>& box, std::vector<c
     box.assign(N, NodeBox{});
     cone_below.assign(N, 0);
     std::vector<double> far_below(N, 0.0);  // per container: largest `far` of its children
+    std::vector<double> drift_below(N, 0.0);  // ... and largest `drift`
+    std::vector<char> aligned_below(N, 1);    // ... and whether all of them have cubes_aligned
     for (int i = N - 1; i >= 0; --i) {      // children come after their parent
         const rt_node& n = d->nodes[i];
         NodeBox& b = box[i];
@@ -2418,7 +2491,11 @@ void node_boxes(const rt_scene_desc* d, std::vector<NodeBox>& box, std::vector<c
         for (int k = 0; k < 3; ++k)
             if (!std::isfinite(lo[k]) || !std::isfinite(hi[k]) || lo[k] > hi[k]) b.ok = false;
         double fwd[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-        if (b.ok && n.xform >= 0 && !affine_forward(d->xforms[n.xform].inv, fwd)) b.ok = false;
+        bool invertible = true;  // wanted for `drift` even where the node has no box
+        if (n.xform >= 0 && !affine_forward(d->xforms[n.xform].inv, fwd)) {
+            b.ok = false;
+            invertible = false;
+        }
         // Bounds on the stretch of the object-to-here map that hold for any affine map (shear, scale
         // after rotation): its largest singular value is at most the Frobenius norm of its 3x3, its
         // smallest at least 1 / the Frobenius norm of the inverse's 3x3.  (Column norms are the
@@ -2430,8 +2507,17 @@ void node_boxes(const rt_scene_desc* d, std::vector<NodeBox>& box, std::vector<c
                 const double v = n.xform >= 0 ? d->xforms[n.xform].inv[row * 4 + k] : (row == k ? 1.0 : 0.0);
                 fro_inv += v * v;
             }
-        const double smax = std::sqrt(fro_fwd), smin = 1.0 / std::sqrt(fro_inv);
+        // an untransformed node stretches nothing (the Frobenius bounds would say sqrt(3) per level)
+        const double smax = n.xform >= 0 ? std::sqrt(fro_fwd) : 1.0, smin = n.xform >= 0 ? 1.0 / std::sqrt(fro_inv) : 1.0;
         b.far = below * smax / (smin * smin);
+        b.drift = (n.type == RT_CUBE ? 1.0 : drift_below[i]) * smax;
+        if (!invertible || !(b.drift >= 0.0)) b.drift = INFINITY;  // also NaN from a degenerate transform
+        bool diagonal = true;  // this node's own transform only scales and translates
+        if (n.xform >= 0) {
+            const double* m = d->xforms[n.xform].inv;
+            diagonal = m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[6] == 0.0 && m[8] == 0.0 && m[9] == 0.0;
+        }
+        b.cubes_aligned = b.drift == 0.0 || (aligned_below[i] && diagonal);  // no cube below: nothing to align
         if (!(smin > 0.0) || !std::isfinite(b.far)) b.ok = false;
         if (b.ok) {
             for (int k = 0; k < 3; ++k) {
@@ -2449,6 +2535,8 @@ void node_boxes(const rt_scene_desc* d, std::vector<NodeBox>& box, std::vector<c
             }
         }
         if (n.parent >= 0) {
+            drift_below[n.parent] = std::fmax(drift_below[n.parent], b.drift);
+            if (!b.cubes_aligned) aligned_below[n.parent] = 0;
             far_below[n.parent] = std::fmax(far_below[n.parent], std::isfinite(b.far) ? b.far : 0.0);
             if (cone_below[i]) cone_below[n.parent] = 1;
         }
@@ -2744,7 +2832,13 @@ struct RecordBuilder {
     }
 };
 
-std::vector<TRec> build_records(const rt_scene_desc* d) {
+// What the device needs to know about the scene's cubes and boxes (see the note on cubes at slabs_f32).
+struct BoxFacts {
+    double drift_max = 0.0;     // the largest NodeBox::drift
+    bool cubes_aligned = true;  // NodeBox::cubes_aligned of every node
+    double extent = 0.0;        // the largest finite |plane| of any box record
+};
+std::vector<TRec> build_records(const rt_scene_desc* d, BoxFacts* facts = nullptr) {
     static const bool no_cull = getenv("RT_NO_CULL") && atoi(getenv("RT_NO_CULL")) != 0;
     RecordBuilder b{};
     b.d = d;
@@ -2753,6 +2847,18 @@ std::vector<TRec> build_records(const rt_scene_desc* d) {
     node_boxes(d, b.box, b.cone_below);
     b.reorder = !(getenv("RT_REORDER") && atoi(getenv("RT_REORDER")) == 0);  // RT_REORDER=0: diagnostic
     b.emit_children(0, d->n_nodes, INFINITY, false);
+    if (facts) {
+        for (const NodeBox& nb : b.box) {
+            facts->drift_max = std::fmax(facts->drift_max, nb.drift);
+            if (!nb.cubes_aligned) facts->cubes_aligned = false;
+        }
+        for (const TRec& r : b.out) {
+            const int type = r.kind & 0xff;
+            if (type != T_CULL && type != RT_GROUP && type != T_CSG_BEGIN) continue;
+            for (int k = 0; k < 6; ++k)
+                if (std::isfinite(r.p[k])) facts->extent = std::fmax(facts->extent, std::fabs(r.p[k]));
+        }
+    }
     return std::move(b.out);
 }
 
@@ -3006,7 +3112,9 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     if (rc != RT_OK) return rc;
     const double t_validated = rtdl::now_ms();
     if (getenv("RT_DUMP_RECORDS")) {  // diagnostic: the traversal records as text, before any device is needed
-        const std::vector<TRec> recs = build_records(d);
+        BoxFacts facts;
+        const std::vector<TRec> recs = build_records(d, &facts);
+        fprintf(stderr, "largest drift %g, cubes aligned %d, extent %g\n", facts.drift_max, (int)facts.cubes_aligned, facts.extent);
         for (size_t k = 0; k < recs.size(); ++k) {
             const TRec& r = recs[k];
             fprintf(stderr, "rec %3zu type %3d flags %#6x node %3d skip %3d ctx %3d  [%g %g %g | %g %g %g] r0 %g r1 %g\n", k, r.kind & 0xff,
@@ -3037,8 +3145,23 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
     }
     {
         const double t0 = rtdl::now_ms();
-        std::vector<TRec> recs = build_records(d);
+        BoxFacts facts;
+        std::vector<TRec> recs = build_records(d, &facts);
         records_ms += rtdl::now_ms() - t0;
+        // see the note on cubes at slabs_f32
+        s->dev.extent_f32 = round_up_f32(facts.extent);
+        s->dev.cube_kappa = 0.0f;
+        s->dev.ym_limit = INFINITY;
+        s->dev.ymin_limit = INFINITY;
+        if (!std::isfinite(facts.drift_max)) {
+            s->dev.ym_limit = 0.0f;  // a degenerate transform above a cube: nothing is decided in single precision
+        } else if (facts.drift_max > 0.0 && facts.cubes_aligned) {
+            s->dev.ym_limit = (float)(0.99 / (RT_EPS * facts.drift_max));
+        } else if (facts.drift_max > 0.0) {
+            const double kappa = 2.0 * 1.4143e-5 * facts.drift_max * 1.001;
+            s->dev.cube_kappa = round_up_f32(kappa);
+            s->dev.ymin_limit = (float)(0.49 / kappa);
+        }
         s->build.n_records = (int32_t)recs.size();
         for (const TRec& r : recs)
             if ((r.kind & 0xff) == T_CULL) ++s->build.n_cull_records;
