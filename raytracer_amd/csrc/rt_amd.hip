@@ -78,7 +78,7 @@ struct alignas(16) TRec {
     int node;    // index into the node table (what a hit reports)
     double r0, r1;  // cylinder / cone minimum, maximum
     double p[12];   // inverse rows | group bounds (6) | triangle p1, e1, e2 (9)
-                    // boxes (T_CULL, groups, CSG begin): p[6..8] = the (low, high) planes per axis as float pairs,
+                    // boxes (T_CULL, groups, CSG begin): p[6..8] = (centre, half width) per axis as float pairs,
                     // p[9] = two float factors of the margin (see slabs_f32 and fill_box_f32)
 };
 static_assert(sizeof(TRec) == 128, "traversal record must be 128 bytes");
@@ -310,34 +310,47 @@ DI V3 reciprocal(V3 d) { return mk(reciprocal1(d.x), reciprocal1(d.y), reciproca
 //   * otherwise the boxes are grown per ray by rho >= kappa |t|: a hit at time t lies within
 //     E + rho + so of the origin along every axis, so |t| <= (E + so + rho) ymin (ymin = smallest |y|)
 //     and rho = 2 kappa ymin (E + so) does while kappa ymin <= 1/2 (E: the largest |plane| of any box
-//     of the scene).  Growing a box by rho is n -+ rho y in the two slab times of an axis, which costs
-//     nothing per box.  Group bounds tests see the grown box too: what it misses the group's own box
-//     misses, and a lane only counts as inside without the f64 test when tmax - tmin exceeds the
-//     margin by 4 rho ym more.
+//     of the scene).  Growing a box by rho is one addition to the half width of each slab.  Group
+//     bounds tests see the grown box too: what it misses the group's own box misses, and a lane only
+//     counts as inside without the f64 test when tmax - tmin exceeds the margin by 4 rho ym more.
 typedef float f2 __attribute__((ext_vector_type(2)));
-constexpr float BOX_F32_2C = 1.9073486328125e-6f;  // 2 * 16 u = 2^-19
-// (planes.x * y + n.x, planes.y * y + n.y), y = the low (slab_lo) or high (slab_hi) half of yy: one
-// packed instruction, the record's planes straight from scalar registers.  The min / max below are
-// written as instructions too: the compiler cannot see that these values are never signalling NaNs
-// and would canonicalise each one.
-DI f2 slab_lo(double planes, f2 yy, f2 n) {
-    f2 t;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(t) : "s"(planes), "v"(yy), "v"(n));
+constexpr float BOX_F32_2C = 2.86102294921875e-6f;  // 2 * 24 u
+// A slab is stored as (centre, half width) c, w: its two times are (c y + n) -+ w |y|, near first,
+// whatever the sign of y, so no minimum / maximum per axis is needed (each costs as much as an f64
+// multiply-add).  The half width is rounded up by the rounding of the centre, so the f32 slab
+// contains the f64 one.  span_*: (m - w a, m + w a) with w from the scalar pair cw and a = |y| from
+// the low / high half of aa: one packed instruction.  (The final three-way min / max are written as
+// instructions too: the compiler cannot see that these values are never signalling NaNs and would
+// canonicalise each one.)
+DI f2 span_lo(double cw, f2 aa, float m) {
+    f2 t, mm;
+    mm.x = m;  // only the low half is read
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0]" : "=v"(t) : "s"(cw), "v"(aa), "v"(mm));
     return t;
 }
-DI f2 slab_hi(double planes, f2 yy, f2 n) {
-    f2 t;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(t) : "s"(planes), "v"(yy), "v"(n));
+DI f2 span_hi(double cw, f2 aa, float m) {
+    f2 t, mm;
+    mm.x = m;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0]" : "=v"(t) : "s"(cw), "v"(aa), "v"(mm));
+    return t;
+}
+// The same with the half width in a vector register (boxes grown per ray, see the note on cubes):
+// wide.x = w + rho.
+DI f2 wide_lo(f2 wide, f2 aa, float m) {
+    f2 t, mm;
+    mm.x = m;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,0] neg_lo:[1,0,0]" : "=v"(t) : "v"(wide), "v"(aa), "v"(mm));
+    return t;
+}
+DI f2 wide_hi(f2 wide, f2 aa, float m) {
+    f2 t, mm;
+    mm.x = m;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0] neg_lo:[1,0,0]" : "=v"(t) : "v"(wide), "v"(aa), "v"(mm));
     return t;
 }
 DI float min_f32(float a, float b) {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-DI float max_f32(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 DI float max3_f32(float a, float b, float c) {
@@ -360,13 +373,35 @@ DI float max3_abs_f32(float a, float b, float c) {
     asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-// px, py, pz: the box's (low, high) planes per axis as two floats in one 8-byte slot of the record.
-// yxy = (1/dx, 1/dy), yz.x = 1/dz; nx, ny, nz: -o/d for the low and for the high plane (they differ by
-// the per-ray growth of the boxes, see the note on cubes).
-DI void slabs_f32(double px, double py, double pz, f2 yxy, f2 yz, f2 nx, f2 ny, f2 nz, float& tmin, float& tmax) {
-    const f2 tx = slab_lo(px, yxy, nx), ty = slab_hi(py, yxy, ny), tz = slab_lo(pz, yz, nz);
-    tmin = max3_f32(min_f32(tx.x, tx.y), min_f32(ty.x, ty.y), min_f32(tz.x, tz.y));
-    tmax = min3_f32(max_f32(tx.x, tx.y), max_f32(ty.x, ty.y), max_f32(tz.x, tz.y));
+// The ray as the box tests see it: 1/d, -o/d and |1/d| per axis (NaN on axes that count as
+// parallel), and by how much the boxes are grown for this ray (see the note on cubes).
+struct BoxRay {
+    f2 yxy, axy, az;  // (1/dx, 1/dy); (|1/dx|, |1/dy|); az.x = |1/dz|
+    float yz;
+    float nx, ny, nz;
+    float rho;
+};
+// px, py, pz: the box's (centre, half width) per axis as two floats in one 8-byte slot of the record.
+template <bool GROW>
+DI void slabs_f32(double px, double py, double pz, const BoxRay& b, float& tmin, float& tmax) {
+    const f2 cx = __builtin_bit_cast(f2, px), cy = __builtin_bit_cast(f2, py), cz = __builtin_bit_cast(f2, pz);
+    const float mx = __builtin_fmaf(cx.x, b.yxy.x, b.nx), my = __builtin_fmaf(cy.x, b.yxy.y, b.ny), mz = __builtin_fmaf(cz.x, b.yz, b.nz);
+    f2 tx, ty, tz;
+    if (GROW) {
+        f2 wx, wy, wz;
+        wx.x = cx.y + b.rho;
+        wy.x = cy.y + b.rho;
+        wz.x = cz.y + b.rho;
+        tx = wide_lo(wx, b.axy, mx);
+        ty = wide_hi(wy, b.axy, my);
+        tz = wide_lo(wz, b.az, mz);
+    } else {
+        tx = span_lo(px, b.axy, mx);
+        ty = span_hi(py, b.axy, my);
+        tz = span_lo(pz, b.az, mz);
+    }
+    tmin = max3_f32(tx.x, ty.x, tz.x);
+    tmax = min3_f32(tx.y, ty.y, tz.y);
 }
 // An f32 that is not below the positive f64 x (or within 1e-38 of it when x is that small).
 DI float up_f32(double x) { return (float)x * 1.00000012f; }
@@ -454,7 +489,7 @@ enum { MODE_CLOSEST = 0, MODE_CONTAINERS = 1, MODE_SHADOW = 2 };
 // XF: the scene has transformed groups or triangles (T_XFORM records); without them the ray never
 // changes space between records and the world-space copy is not kept.
 // CULL: the scene has T_CULL records.  CSGM: it has CSG shapes.
-template <int MODE, bool XF, bool CULL, bool CSGM>
+template <int MODE, bool XF, bool CULL, bool CSGM, bool GROW>
 DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
     constexpr bool TRACK = MODE == MODE_CONTAINERS;
     if (!TRACK) {
@@ -484,8 +519,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     // largest |1 / d|, a bound on |o|^2 times that, and the parts of the margins that do not depend
     // on the box.  hlim: no time beyond it counts (the light's distance for a shadow ray, then the
     // nearest hit so far; for the container pass only times <= 0 count).
-    f2 yxy, yz, nx, ny, nz;
-    float ym, osq_ym, c_cull, c_group, grow4;
+    BoxRay box;
+    float ym, osq_ym, c_cull, c_group, grow4 = 0.0f;
     float hlim = TRACK ? 0.0f : (MODE == MODE_SHADOW ? up_f32(limit) : INFINITY);
     bool cfin;   // no axis of this lane's ray counts as parallel to a slab
     bool plain;  // wave-uniform: every active lane's ray has finite components below 1e15 (see T_DIAG)
@@ -501,24 +536,20 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         const float so = (fabsf(ox) + fabsf(oy)) + fabsf(oz);
         const float sd = (fabsf(dx) + fabsf(dy)) + fabsf(dz);
         const bool bounded = (so + sd) <= 1e15f;  // false for NaN and infinite components too
-        // per-ray growth of the boxes (scenes with cubes that are not axis-aligned, else zero)
         const float mx = -(ox * yx), my = -(oy * yy), mz = -(oz * yzz);
-        yxy = (f2){yx, yy};
-        yz = (f2){yzz, 0.0f};
+        box.yxy = (f2){yx, yy};
+        box.yz = yzz;
+        box.axy = (f2){fabsf(yx), fabsf(yy)};
+        box.az.x = fabsf(yzz);
         bool tame = bounded && ym <= S.ym_limit;
-        if (S.cube_kappa != 0.0f) {  // scenes with cubes that are not axis-aligned
+        box.nx = mx;
+        box.ny = my;
+        box.nz = mz;
+        if (GROW) {  // scenes with cubes that are not axis-aligned
             const float ymin = min3_abs_f32(yx, yy, yzz);
-            const float rho = (S.cube_kappa * ymin) * (S.extent_f32 + so);
+            box.rho = (S.cube_kappa * ymin) * (S.extent_f32 + so);
             tame = tame && ymin <= S.ymin_limit;
-            nx = (f2){__builtin_fmaf(-rho, yx, mx), __builtin_fmaf(rho, yx, mx)};
-            ny = (f2){__builtin_fmaf(-rho, yy, my), __builtin_fmaf(rho, yy, my)};
-            nz = (f2){__builtin_fmaf(-rho, yzz, mz), __builtin_fmaf(rho, yzz, mz)};
-            grow4 = (4.0f * rho) * ym;
-        } else {
-            nx = (f2){mx, mx};
-            ny = (f2){my, my};
-            nz = (f2){mz, mz};
-            grow4 = 0.0f;
+            grow4 = (4.0f * box.rho) * ym;
         }
         const float osq = so * so;             // >= |o|^2
         const float cc = __builtin_fmaf(ym * BOX_F32_2C, so, 1e-30f);
@@ -634,7 +665,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // Padded box in front of a leaf or a run of siblings, tested in single precision (see
             // slabs_f32): p[6..8] hold the planes as floats, p[9] the margin's two box-dependent factors.
             float tmin, tmax;
-            slabs_f32(q[6], q[7], q[8], yxy, yz, nx, ny, nz, tmin, tmax);
+            slabs_f32<GROW>(q[6], q[7], q[8], box, tmin, tmax);
             const f2 kk = __builtin_bit_cast(f2, q[9]);
             const float G = __builtin_fmaf(kk.y, osq_ym, __builtin_fmaf(kk.x, ym, c_cull));
             // (lane masks of the single comparisons, combined as scalars: a ballot of the combined
@@ -813,11 +844,11 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // margin; the others (and lanes with an axis that counts as parallel, which the f32 test
             // ignores but the reference does not) repeat the test in f64 exactly as the reference does.
             float tmin, tmax;
-            slabs_f32(q[6], q[7], q[8], yxy, yz, nx, ny, nz, tmin, tmax);
+            slabs_f32<GROW>(q[6], q[7], q[8], box, tmin, tmax);
             const float G = __builtin_fmaf(__builtin_bit_cast(f2, q[9]).x, ym, c_group);
             const float gap = tmin - tmax;
             bool miss = gap > G;
-            const bool unsure = act && (!(miss || (gap + grow4) < -G) || !cfin);
+            const bool unsure = act && (!(miss || (GROW ? gap + grow4 : gap) < -G) || !cfin);
             if (wave_ballot(unsure) != 0ull) {
                 double e0, e1;
                 slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], e0, e1);
@@ -1318,7 +1349,7 @@ DI void primary_ray(const DevJob& J, int px, int py, V3& ro, V3& rd) {
 // of a tile at the edge of a mirror sees the background, but some of its pixels do not: such a tile
 // started among the last ones is what the whole frame then waits for).  The render kernel takes the
 // tiles class 2 first.  This only permutes the order in which tiles are rendered.
-template <bool XF, bool CULL, bool CSGM>
+template <bool XF, bool CULL, bool CSGM, bool GROW = false>
 __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, long long n_tiles, int probe_bounces,
                                                         int* __restrict__ tile_class) {
     const int lane = threadIdx.x;
@@ -1332,7 +1363,7 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
     V3 ro, rd;
     primary_ray(J, px, py, ro, rd);
     Hit h;
-    trace<MODE_CLOSEST, XF, CULL, CSGM>(S, active, ro, rd, 0.0, h);
+    trace<MODE_CLOSEST, XF, CULL, CSGM, GROW>(S, active, ro, rd, 0.0, h);
     int cls = 0;
     if (active && h.found) {
         const RT_CONST SRec* sr = S.shade + h.node;
@@ -1352,7 +1383,7 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
             ro = point + (n * RT_EPS);
             rd = reflect(rd, n);
         }
-        trace<MODE_CLOSEST, XF, CULL, CSGM>(S, follow, ro, rd, 0.0, h);
+        trace<MODE_CLOSEST, XF, CULL, CSGM, GROW>(S, follow, ro, rd, 0.0, h);
         if (follow) {
             if (!h.found)
                 h.node = -1;
@@ -1456,7 +1487,9 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& row_in_til
 // SHARE: lanes without work take over refraction subtrees of busy lanes (see L_*).  Used for frames
 // small enough that their time is that of their longest wavefront; on large frames the GPU is busy
 // anyway and the bookkeeping only costs.
-template <bool TRACK, bool XF, bool CULL, bool CSGM, bool SHARE = false>
+// GROW: the scene has cubes that are not axis-aligned in the spaces their boxes are tested in (see the
+// note on cubes at slabs_f32); only instantiated for the most general combinations of the others.
+template <bool TRACK, bool XF, bool CULL, bool CSGM, bool SHARE = false, bool GROW = false>
 __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAVES) rt_kernel(DevScene S, DevJob J, double* __restrict__ out,
                                                  unsigned long long* __restrict__ counters,
                                                  unsigned long long* __restrict__ clear_counters) {
@@ -1534,14 +1567,14 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
 #ifdef RT_PROFILE
         unsigned long long pt = __builtin_amdgcn_s_memtime();
 #endif
-        trace<MODE_CLOSEST, XF, CULL, CSGM>(S, pending, ro, rd, 0.0, h);
+        trace<MODE_CLOSEST, XF, CULL, CSGM, GROW>(S, pending, ro, rd, 0.0, h);
         RT_MIX_ADD(h);
         if (TRACK) {
             // n1/n2 (world.rs:99-132) are only read when the hit material is transparent
             // (world.rs:185, 243-246): only those lanes run the container pass.
             const bool need = pending && h.found && S.shade[h.node].transp != 0.0;
             if (wave_ballot(need) != 0ull) {
-                trace<MODE_CONTAINERS, XF, CULL, CSGM>(S, need, ro, rd, 0.0, h);
+                trace<MODE_CONTAINERS, XF, CULL, CSGM, GROW>(S, need, ro, rd, 0.0, h);
                 RT_MIX_ADD(h);
             }
         }
@@ -1689,7 +1722,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
             park[10][lane] = acc.y;
             park[11][lane] = acc.z;
             asm volatile("" ::: "memory");  // the values must really leave the registers ...
-            trace<MODE_SHADOW, XF, CULL, CSGM>(S, shadow_matters, over, lightv, distance, sh);
+            trace<MODE_SHADOW, XF, CULL, CSGM, GROW>(S, shadow_matters, over, lightv, distance, sh);
             RT_MIX_ADD(sh);
             asm volatile("" ::: "memory");  // ... and come back from LDS, not from a copy the compiler kept
             normalv = mk(park[0][lane], park[1][lane], park[2][lane]);
@@ -2382,22 +2415,30 @@ float round_up_f32(double v) {
     if ((double)f < v) f = std::nextafterf(f, INFINITY);
     return f;
 }
-// The single-precision image of a box for the device's slabs_f32: planes rounded to nearest, and the
-// two factors of the margin that depend on the box: k0 = 2 * 16 u * (largest |plane|) + pad0 (times the
-// largest |1 / d| of the ray) and k1 = pad1 (times a bound on |o|^2 / |d|).  An infinite box gets an
-// infinite k0: nothing is then decided in single precision.
+// The single-precision image of a box for the device's slabs_f32: per axis the centre rounded to
+// nearest and the half width rounded up by at least the centre's rounding, so that the f32 box
+// contains the f64 one; and the two factors of the margin that depend on the box: k0 = 2 * 24 u *
+// (largest |plane|) + pad0 (times the largest |1 / d| of the ray) and k1 = pad1 (times a bound on
+// |o|^2 / |d|).  An infinite box gets an infinite k0: nothing is then decided in single precision.
 void fill_box_f32(TRec& r, const double bmin[3], const double bmax[3], double pad0, double pad1) {
-    float planes[6], kk[2];
+    float cw[6], kk[2];
     double reach = 0.0;
     for (int k = 0; k < 3; ++k) {
-        planes[2 * k] = (float)bmin[k];
-        planes[2 * k + 1] = (float)bmax[k];
+        const double half = 0.5 * (bmax[k] - bmin[k]), centre = bmin[k] + half;
+        float c = (float)centre;
+        float w = round_up_f32(std::fabs(half) + std::fabs((double)c - centre));
+        if (!std::isfinite(c) || !std::isfinite(w)) {  // unbounded along this axis
+            c = 0.0f;
+            w = INFINITY;
+        }
+        cw[2 * k] = c;
+        cw[2 * k + 1] = w;
         reach = std::fmax(reach, std::fmax(std::fabs(bmin[k]), std::fabs(bmax[k])));
     }
-    const double k0 = (1.9073486328125e-6 * reach + pad0) * (1.0 + 1e-6);
+    const double k0 = (2.86102294921875e-6 * reach + pad0) * (1.0 + 1e-6);
     kk[0] = std::isfinite(k0) && reach <= 1e15 ? round_up_f32(k0) : INFINITY;  // NaN planes too
     kk[1] = round_up_f32(pad1 * (1.0 + 1e-6));
-    std::memcpy(&r.p[6], planes, sizeof planes);
+    std::memcpy(&r.p[6], cw, sizeof cw);
     std::memcpy(&r.p[9], kk, sizeof kk);
 }
 
@@ -2978,6 +3019,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
     job.split = 1;
     job.extra_blocks = 0;
     bool share = false;
+    const bool grow = s->dev.cube_kappa != 0.0f;
     if (job.tile_order && s->any_transparent && !s->any_csg) {
         static const int split_env = getenv("RT_SPLIT") ? atoi(getenv("RT_SPLIT")) : 0;
         // measured on the default scene: 8,100 tiles 0.42 -> 0.25 ms with four strips, 32,400 tiles
@@ -3003,7 +3045,8 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
         using Pre = void (*)(DevScene, DevJob, long long, int, int*);
         static const Pre pres[4] = {tile_class_kernel<false, false, false>, tile_class_kernel<false, true, false>,
                                     tile_class_kernel<true, false, false>, tile_class_kernel<true, true, false>};
-        Pre prek = s->any_csg ? tile_class_kernel<true, true, true> : pres[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
+        Pre prek = s->any_csg ? tile_class_kernel<true, true, true, true> : pres[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
+        if (grow && !s->any_csg) prek = s->any_xform ? tile_class_kernel<true, true, false, true> : tile_class_kernel<false, true, false, true>;
         int* classes = order + 3 * tiles;
         static const int probe_env = getenv("RT_PROBE") ? atoi(getenv("RT_PROBE")) : 2;  // diagnostic
         const int probe = share ? probe_env : 0;  // mirrors only matter for the strips
@@ -3025,7 +3068,13 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
                                           rt_kernel<true, true, false, false, true>, rt_kernel<true, true, true, false, true>};
         if (share) kernel = sharing[(s->any_xform ? 2 : 0) | (s->any_cull ? 1 : 0)];
         // scenes with CSG shapes are rare: they share the two most general variants
-        if (s->any_csg) kernel = s->any_transparent ? rt_kernel<true, true, true, true> : rt_kernel<false, true, true, true>;
+        if (grow) {  // boxes grown per ray (always with T_CULL support: cubes have boxes)
+            static const Kernel growing[4] = {rt_kernel<false, false, true, false, false, true>, rt_kernel<false, true, true, false, false, true>,
+                                              rt_kernel<true, false, true, false, false, true>, rt_kernel<true, true, true, false, false, true>};
+            kernel = growing[(s->any_transparent ? 2 : 0) | (s->any_xform ? 1 : 0)];
+            if (share) kernel = s->any_xform ? rt_kernel<true, true, true, false, true, true> : rt_kernel<true, false, true, false, true, true>;
+        }
+        if (s->any_csg) kernel = s->any_transparent ? rt_kernel<true, true, true, true, false, true> : rt_kernel<false, true, true, true, false, true>;
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, mine,
                            clears_other ? other : nullptr);
         HIP_TRY(hipGetLastError());

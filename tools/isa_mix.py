@@ -11,7 +11,7 @@ import collections
 import re
 import sys
 
-KERNEL = sys.argv[1] if len(sys.argv) > 1 else "rt_kernelILb1ELb0ELb1ELb0ELb0E"
+KERNEL = sys.argv[1] if len(sys.argv) > 1 else "rt_kernelILb1ELb0ELb1ELb0ELb0ELb0E"
 
 
 def classify(op):

@@ -3,7 +3,7 @@ import collections, re, sys, importlib.util, os
 spec = importlib.util.spec_from_file_location('isa_mix', os.path.join(os.path.dirname(__file__), 'isa_mix.py'))
 m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 path = sys.argv[1]
-K = sys.argv[2] if len(sys.argv) > 2 else "rt_kernelILb1ELb0ELb1ELb0ELb0E"
+K = sys.argv[2] if len(sys.argv) > 2 else "rt_kernelILb1ELb0ELb1ELb0ELb0ELb0E"
 text = open(path).read()
 mm = re.search(r"^(_ZN\S*%s\S*):" % re.escape(K), text, flags=re.M)
 lines = text[mm.end():text.index(".Lfunc_end", mm.end())].split("\n")
