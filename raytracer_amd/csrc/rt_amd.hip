@@ -67,12 +67,14 @@ namespace {
 // collect their intersections per lane instead of competing for the nearest hit; the end record
 // sorts and filters them.
 enum { T_XFORM = 8, T_CULL = 9, T_CSG_BEGIN = 10, T_CSG_END = 11, T_HAS_INV = 0x100, T_CLOSED = 0x200,
-       T_OWN_XFORM = 0x400, T_LINE_ONLY = 0x800, T_CSG_OP_SHIFT = 12, T_DIAG = 0x4000 };
+       T_OWN_XFORM = 0x400, T_LINE_ONLY = 0x800, T_CSG_OP_SHIFT = 12, T_DIAG = 0x4000, T_LEVELS_SHIFT = 16 };
 struct alignas(16) TRec {
     int kind;    // low byte: RT_* type or T_XFORM; T_HAS_INV: p holds rows 0..2 of the inverse; T_CLOSED;
                  // T_DIAG: that inverse is a scale and a translation (its six off-diagonal entries are zeros);
                  // T_OWN_XFORM: the record before this one is this node's T_XFORM record;
-                 // T_LINE_ONLY (groups): hits below can lie outside the box, test the ray's line only
+                 // T_LINE_ONLY (groups): hits below can lie outside the box, test the ray's line only;
+                 // bits 16-17: how many untransformed levels (0, 1, 2 or more) lie between the space the walk keeps
+                 // the ray in and the space this record tests or transforms it in (see through_identity)
     int skip;    // first record after this node's subtree
     int ctx;     // record holding the inverse of the nearest enclosing transformed group, or -1
     int node;    // index into the node table (what a hit reports)
@@ -199,8 +201,21 @@ DI V3 to_object(const DevScene& S, const RT_CONST SRec* r, V3 p) {
     if (r->flags & S_HAS_XFORM) p = xpoint(r->inv, p);
     return p;
 }
+// The reference multiplies a ray by the inverse of EVERY level's transform on its way down
+// (Shape::intersect, shape.rs:23-29), the identity matrices of untransformed groups and shapes
+// included.  For finite rays that changes nothing (at most the sign of a zero, which no test can
+// tell) and the walk skips it; a ray with an infinite or NaN component comes out different: 0 * inf
+// is NaN, so after one level every OTHER component is NaN too and after two all are.  Walks of
+// wavefronts that carry such a ray apply the levels (`times` saturates at 2: a third changes nothing).
+DI void through_identity(int times, V3& o, V3& d) {
+    for (int k = 0; k < times; ++k) {
+        o = mk((o.x + 0.0 * o.y) + 0.0 * o.z, (0.0 * o.x + o.y) + 0.0 * o.z, (0.0 * o.x + 0.0 * o.y) + o.z);
+        d = mk((d.x + 0.0 * d.y) + 0.0 * d.z, (0.0 * d.x + d.y) + 0.0 * d.z, (0.0 * d.x + 0.0 * d.y) + d.z);
+    }
+}
 // The same for a ray during traversal, on the traversal records (`ctx` is a record index there).
-DI void chain_ray(const DevScene& S, int ctx, V3& o, V3& d) {
+// wild: see through_identity.
+DI void chain_ray(const DevScene& S, int ctx, bool wild, V3& o, V3& d) {
     int c[RT_MAX_XFORM_NEST];
     c[0] = ctx;
 #pragma unroll
@@ -209,6 +224,7 @@ DI void chain_ray(const DevScene& S, int ctx, V3& o, V3& d) {
     for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
         if (c[k] >= 0) {
             const RT_CONST double* m = S.trav[c[k]].p;
+            if (wild) through_identity((S.trav[c[k]].kind >> T_LEVELS_SHIFT) & 3, o, d);
             o = xpoint(m, o);
             d = xvec(m, d);
         }
@@ -560,6 +576,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         plain = wave_ballot(active && !bounded) == 0ull;
     };
     ray_changed();
+    const bool wild = !plain;  // wave-uniform: some lane's ray (as given) has an infinite, NaN or huge component: see through_identity
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
     int csg_depth = 0;  // open CSG shapes around the current record (wave-uniform)
     CsgList cl;
@@ -637,7 +654,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (XF && ctx != cur_ctx) {
             co = wo;
             cd = wd;
-            chain_ray(S, ctx, co, cd);
+            chain_ray(S, ctx, wild, co, cd);
             ray_changed();
             cur_ctx = ctx;
         }
@@ -645,6 +662,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (XF && type == T_XFORM) {
             // The inverse of a transformed group (or triangle): the records after it, up to the
             // end of the node's subtree, see the ray in that node's space.
+            if (wild) through_identity((kind >> T_LEVELS_SHIFT) & 3, co, cd);
             V3 to = xpoint(q, co), td = xvec(q, cd);
             co = to;
             cd = td;
@@ -851,7 +869,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             const bool unsure = act && (!(miss || (GROW ? gap + grow4 : gap) < -G) || !cfin);
             if (wave_ballot(unsure) != 0ull) {
                 double e0, e1;
-                slabs(co, cd, q[0], q[1], q[2], q[3], q[4], q[5], e0, e1);
+                V3 go = co, gd = cd;
+                if (wild) through_identity((kind >> T_LEVELS_SHIFT) & 3, go, gd);
+                slabs(go, gd, q[0], q[1], q[2], q[3], q[4], q[5], e0, e1);
                 miss = unsure ? (e0 > e1) : miss;
             }
             bool inside = act && !miss;
@@ -872,6 +892,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             continue;
         }
         V3 lo = co, ld = cd;
+        if (wild) through_identity((kind >> T_LEVELS_SHIFT) & 3, lo, ld);
         if ((kind & T_DIAG) && plain) {
             // The same products and sums with the terms left out that are exact zeros: 0 * finite is
             // +-0, and x + (+-0) is x, except that an exact zero may come out with the other sign; no
@@ -880,8 +901,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             lo = mk(q[0] * co.x + q[3], q[5] * co.y + q[7], q[10] * co.z + q[11]);
             ld = mk(q[0] * cd.x, q[5] * cd.y, q[10] * cd.z);
         } else if (kind & T_HAS_INV) {  // Shape::intersect: world_ray.transform(inverse) (shape.rs:24-26, ray.rs:30-35)
-            lo = xpoint(q, co);
-            ld = xvec(q, cd);
+            const V3 po = lo, pd = ld;
+            lo = xpoint(q, po);
+            ld = xvec(q, pd);
         }
 
         begin_leaf(rnode);
@@ -2804,9 +2826,13 @@ struct RecordBuilder {
         int flags = (n.flags & RT_NODE_CLOSED) ? T_CLOSED : 0;
         rec[i] = (int)out.size();
         int extra = -1;  // this node's T_XFORM or T_CULL record
+        // untransformed levels between this node and the space the walk keeps the ray in (see through_identity)
+        int levels = 0;
+        for (int a = n.parent; a >= 0 && a != n.ctx && levels < 2; a = d->nodes[a].parent) ++levels;
         if (n.xform >= 0 && own_payload(n)) {
             TRec x = r;
-            x.kind = T_XFORM | T_HAS_INV;
+            x.kind = T_XFORM | T_HAS_INV | (levels << T_LEVELS_SHIFT);
+            levels = -1;  // the node itself is then tested in its own space
             std::memcpy(x.p, d->xforms[n.xform].inv, sizeof x.p);
             extra = (int)out.size();
             out.push_back(x);
@@ -2830,7 +2856,8 @@ struct RecordBuilder {
                     flags |= T_DIAG;
             }
         }
-        r.kind = (n.type == RT_CSG ? (int)T_CSG_BEGIN : n.type) | flags;
+        if (n.xform < 0) ++levels;  // its own identity matrix
+        r.kind = (n.type == RT_CSG ? (int)T_CSG_BEGIN : n.type) | flags | ((levels < 0 ? 0 : (levels > 2 ? 2 : levels)) << T_LEVELS_SHIFT);
         double inner = INFINITY;
         if (container(n)) {
             const double* mn = d->aabbs[n.data].min;

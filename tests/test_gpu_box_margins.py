@@ -103,8 +103,8 @@ def test_scene_far_from_the_origin_or_of_unusual_size(host, orc, offset, scale):
 
 
 def test_rays_beyond_the_range_of_the_shortcut(host, orc):
-    """Components of 1e15 and more, up to values whose squares overflow f64: the walk must fall back to
-    the exact tests, whatever they make of such rays."""
+    """Components of 1e15 and more, up to values whose squares overflow f64, infinite and NaN
+    components: the walk must fall back to the exact tests, whatever they make of such rays."""
     rng = np.random.default_rng(19)
     origins, dirs = [], []
     for mag in (1e14, 1e15, 1e16, 1e20, 1e38, 1e40, 1e155, 1e300):
@@ -120,6 +120,18 @@ def test_rays_beyond_the_range_of_the_shortcut(host, orc):
                 d = d / n if np.isfinite(n) and n > 0 else d
             origins.append(o)
             dirs.append(d)
+    for bad in (np.inf, -np.inf, np.nan):   # the reference's identity matrices turn 0 * inf into NaN level by level
+        for axis in range(3):
+            for o in (np.array([0.5, 0.25, -20.0]), np.array([1.5, 0.1, -20.0]), np.array([-3.0, 1.5, -20.0])):
+                d = np.array([0.0, 0.0, 1.0])
+                o2 = o.copy()
+                o2[axis] = bad
+                origins.append(o2)
+                dirs.append(d)
+                d2 = d.copy()
+                d2[axis] = bad
+                origins.append(o)
+                dirs.append(d2)
     # unnormalised directions, very long and very short
     for s in (1e-30, 1e-4, 1e10, 1e200):
         for _ in range(20):
