@@ -1034,6 +1034,19 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
 // the parent.  Identity levels skip the product but not the normalisation; once the magnitude is
 // exactly 1.0 further identity levels cannot change the vector, so the walk jumps to the next
 // enclosing non-identity group.
+// m = |n|, n = n / m for a vector that has been normalised before.  Its squared length is then
+// very often exactly 1.0 (always for the axis-parallel normals of cubes and planes), the root of
+// 1.0 is 1.0 and x / 1.0 is x: when that holds for every lane that takes part, the root and the three
+// divisions are left out.
+DI void renormalise(V3& n, double& m) {
+    const double dd = dot(n, n);
+    if (wave_ballot(dd != 1.0) != 0ull) {
+        m = sqrt(dd);
+        n = n / m;
+    } else {
+        m = 1.0;
+    }
+}
 template <bool XF>
 DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
     if (r->flags & S_HAS_XFORM) n = xnormal(r->inv_t, n);
@@ -1043,8 +1056,7 @@ DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
     int level = 1;
     if (!XF) {  // only identity ancestors: normalise until the length is exactly 1
         while (level < n_levels && m != 1.0) {
-            m = magnitude(n);
-            n = n / m;
+            renormalise(n, m);
             ++level;
         }
         return n;
@@ -1054,8 +1066,7 @@ DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
         const int xf = k < RT_MAX_XFORM_NEST ? r->anc_xf[k] : -1;
         const int stop = xf >= 0 ? r->anc_level[k < RT_MAX_XFORM_NEST ? k : 0] : n_levels;
         while (level < stop && m != 1.0) {  // identity ancestors: normalise only
-            m = magnitude(n);
-            n = n / m;
+            renormalise(n, m);
             ++level;
         }
         if (xf < 0) break;
