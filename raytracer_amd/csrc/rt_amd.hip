@@ -333,37 +333,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 constexpr float BOX_F32_2C = 2.86102294921875e-6f;  // 2 * 24 u
 // A slab is stored as (centre, half width) c, w: its two times are (c y + n) -+ w |y|, near first,
 // whatever the sign of y, so no minimum / maximum per axis is needed (each costs as much as an f64
-// multiply-add).  The half width is rounded up by the rounding of the centre, so the f32 slab
-// contains the f64 one.  span_*: (m - w a, m + w a) with w from the scalar pair cw and a = |y| from
-// the low / high half of aa: one packed instruction.  (The final three-way min / max are written as
-// instructions too: the compiler cannot see that these values are never signalling NaNs and would
-// canonicalise each one.)
-DI f2 span_lo(double cw, f2 aa, float m) {
-    f2 t, mm;
-    mm.x = m;  // only the low half is read
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0] neg_lo:[1,0,0]" : "=v"(t) : "s"(cw), "v"(aa), "v"(mm));
-    return t;
-}
-DI f2 span_hi(double cw, f2 aa, float m) {
-    f2 t, mm;
-    mm.x = m;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,1,0] op_sel_hi:[1,1,0] neg_lo:[1,0,0]" : "=v"(t) : "s"(cw), "v"(aa), "v"(mm));
-    return t;
-}
-// The same with the half width in a vector register (boxes grown per ray, see the note on cubes):
-// wide.x = w + rho.
-DI f2 wide_lo(f2 wide, f2 aa, float m) {
-    f2 t, mm;
-    mm.x = m;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[0,0,0] neg_lo:[1,0,0]" : "=v"(t) : "v"(wide), "v"(aa), "v"(mm));
-    return t;
-}
-DI f2 wide_hi(f2 wide, f2 aa, float m) {
-    f2 t, mm;
-    mm.x = m;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[0,1,0] neg_lo:[1,0,0]" : "=v"(t) : "v"(wide), "v"(aa), "v"(mm));
-    return t;
-}
+// multiply-add): three single-precision multiply-adds per axis, |y| as an operand modifier.  The
+// half width is rounded up by the rounding of the centre, so the f32 slab contains the f64 one.
+// (The final three-way min / max are written as instructions: the compiler cannot see that these
+// values are never signalling NaNs and would canonicalise each one.)
 DI float min_f32(float a, float b) {
     float r;
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -389,11 +362,10 @@ DI float max3_abs_f32(float a, float b, float c) {
     asm("v_max3_f32 %0, |%1|, |%2|, |%3|" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
-// The ray as the box tests see it: 1/d, -o/d and |1/d| per axis (NaN on axes that count as
-// parallel), and by how much the boxes are grown for this ray (see the note on cubes).
+// The ray as the box tests see it: 1/d and -o/d per axis (NaN on axes that count as parallel), and
+// by how much the boxes are grown for this ray (see the note on cubes).
 struct BoxRay {
-    f2 yxy, axy, az;  // (1/dx, 1/dy); (|1/dx|, |1/dy|); az.x = |1/dz|
-    float yz;
+    float yx, yy, yz;
     float nx, ny, nz;
     float rho;
 };
@@ -401,23 +373,10 @@ struct BoxRay {
 template <bool GROW>
 DI void slabs_f32(double px, double py, double pz, const BoxRay& b, float& tmin, float& tmax) {
     const f2 cx = __builtin_bit_cast(f2, px), cy = __builtin_bit_cast(f2, py), cz = __builtin_bit_cast(f2, pz);
-    const float mx = __builtin_fmaf(cx.x, b.yxy.x, b.nx), my = __builtin_fmaf(cy.x, b.yxy.y, b.ny), mz = __builtin_fmaf(cz.x, b.yz, b.nz);
-    f2 tx, ty, tz;
-    if (GROW) {
-        f2 wx, wy, wz;
-        wx.x = cx.y + b.rho;
-        wy.x = cy.y + b.rho;
-        wz.x = cz.y + b.rho;
-        tx = wide_lo(wx, b.axy, mx);
-        ty = wide_hi(wy, b.axy, my);
-        tz = wide_lo(wz, b.az, mz);
-    } else {
-        tx = span_lo(px, b.axy, mx);
-        ty = span_hi(py, b.axy, my);
-        tz = span_lo(pz, b.az, mz);
-    }
-    tmin = max3_f32(tx.x, ty.x, tz.x);
-    tmax = min3_f32(tx.y, ty.y, tz.y);
+    const float mx = __builtin_fmaf(cx.x, b.yx, b.nx), my = __builtin_fmaf(cy.x, b.yy, b.ny), mz = __builtin_fmaf(cz.x, b.yz, b.nz);
+    const float wx = GROW ? cx.y + b.rho : cx.y, wy = GROW ? cy.y + b.rho : cy.y, wz = GROW ? cz.y + b.rho : cz.y;
+    tmin = max3_f32(__builtin_fmaf(-wx, fabsf(b.yx), mx), __builtin_fmaf(-wy, fabsf(b.yy), my), __builtin_fmaf(-wz, fabsf(b.yz), mz));
+    tmax = min3_f32(__builtin_fmaf(wx, fabsf(b.yx), mx), __builtin_fmaf(wy, fabsf(b.yy), my), __builtin_fmaf(wz, fabsf(b.yz), mz));
 }
 // An f32 that is not below the positive f64 x (or within 1e-38 of it when x is that small).
 DI float up_f32(double x) { return (float)x * 1.00000012f; }
@@ -553,10 +512,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         const float sd = (fabsf(dx) + fabsf(dy)) + fabsf(dz);
         const bool bounded = (so + sd) <= 1e15f;  // false for NaN and infinite components too
         const float mx = -(ox * yx), my = -(oy * yy), mz = -(oz * yzz);
-        box.yxy = (f2){yx, yy};
+        box.yx = yx;
+        box.yy = yy;
         box.yz = yzz;
-        box.axy = (f2){fabsf(yx), fabsf(yy)};
-        box.az.x = fabsf(yzz);
         bool tame = bounded && ym <= S.ym_limit;
         box.nx = mx;
         box.ny = my;

@@ -54,7 +54,7 @@ def main():
     end = text.index(".Lfunc_end", start)
     lines = text[start:end].split("\n")
     # first inner loop: from its header label to the next loop header at the same depth
-    heads = [i for i, l in enumerate(lines) if "Inner Loop Header: Depth=2" in l]
+    heads = [i for i, l in enumerate(lines) if "Loop Header: Depth=2" in l]  # the walks (they may contain small loops)
     lo, hi = heads[0] - 1, heads[1] - 1
     print("kernel %s\nloop: lines %d..%d of the function" % (m.group(1)[:90], lo, hi))
     block, rows, total = "entry", [], collections.Counter()
