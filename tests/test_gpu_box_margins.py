@@ -102,6 +102,60 @@ def test_scene_far_from_the_origin_or_of_unusual_size(host, orc, offset, scale):
     same_colours(host, orc, lambda api: boxes_world(api, offset=offset, scale=scale), o, d)
 
 
+def nested_world(api, seed):
+    """The same kind of shapes under two levels of rotated, sheared and scaled groups, some of them divided:
+    boxes are tested in the groups' spaces, cubes are not axis-aligned there, and the ray changes
+    space on the way down."""
+    M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+    rng = np.random.default_rng(seed)
+
+    def shape(k):
+        c = rng.integers(-3, 4, 3).astype(float)
+        size = float(rng.choice([0.4, 0.7, 1.0]))
+        mat = Phong(Solid(Color(*rng.uniform(0.2, 1.0, 3))), 0.1, 0.7, 0.0, 50.0, 0.2 if k % 2 else 0.0, 0.0, 1.0)
+        xf = M.translation(c[0], c[1], c[2]) * M.rotation_z(float(rng.uniform(0, 3))) * M.scaling(size, size * 0.8, size)
+        kind = k % 3
+        if kind == 0:
+            return api.Cube(xf, mat, True)
+        if kind == 1:
+            return api.Sphere(xf, mat, True)
+        return api.Cylinder(xf, mat, True, -1.0, 1.0, True)
+
+    outer = api.Group(M.rotation_y(0.4) * M.shearing(0.2, 0.0, 0.0, 0.1, 0.0, 0.0))
+    for g in range(3):
+        inner = api.Group(M.translation(4.0 * (g - 1), 0.5 * g, 1.0) * M.rotation_x(0.3 * g) * M.scaling(1.0 + 0.5 * g, 1.0, 0.75))
+        inner.add_children([shape(3 * g + k) for k in range(5)])
+        if g != 1:
+            inner.divide(2)
+        outer.add_child(inner)
+    loose = [shape(20 + k) for k in range(3)]
+    return api.World([outer] + loose, [api.PointLight(api.point(15.0, 25.0, -20.0), Color(1.0, 1.0, 1.0))])
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_edge_rays_through_transformed_groups(host, orc, seed):
+    """Rays aimed at the corners and edges of the boxes the walk tests (the shapes' boxes in their
+    groups' spaces, mapped to world space) and right past them."""
+    rng = np.random.default_rng(100 + seed)
+    origins, dirs = [], []
+    for _ in range(500):
+        t = rng.uniform(-7, 7, 3) * np.array([1.0, 0.5, 0.6])
+        for dist in (14.0, 300.0):
+            o = rng.normal(size=3)
+            o = o / np.linalg.norm(o) * dist
+            for eps in (0.0, 1e-12, 1e-7, 1e-5, 1e-3):
+                d = t + eps * rng.choice([-1.0, 0.0, 1.0], 3) * dist - o
+                if rng.random() < 0.15:
+                    d[rng.integers(0, 3)] = 0.0
+                n = np.linalg.norm(d)
+                if n > 0:
+                    origins.append(o)
+                    dirs.append(d / n)
+    o, d = np.array(origins), np.array(dirs)
+    ref = same_colours(host, orc, lambda api: nested_world(api, seed), o, d, remaining=3)
+    assert 0.05 < (ref != 0).any(axis=1).mean() < 0.95
+
+
 def test_rays_beyond_the_range_of_the_shortcut(host, orc):
     """Components of 1e15 and more, up to values whose squares overflow f64, infinite and NaN
     components: the walk must fall back to the exact tests, whatever they make of such rays."""
