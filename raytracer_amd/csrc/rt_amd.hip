@@ -2590,11 +2590,11 @@ struct RecordBuilder {
     static constexpr int CLUSTER_MIN = 2;
     // Tuned on the default scene, a scene of loose quadrics and three divided meshes (870 k
     // triangles the largest); the frame times move by a few percent over 1..4, 1..3, 1.5..4, 0.3..0.9.
-    static constexpr double need = 2.0;        // expected saved visits a run's box must reach
-    static constexpr double cost_quad = 1.0;   // visit costs in units of one T_CULL test: a leaf's own T_CULL record,
-    static constexpr double cost_tri = 1.5;    // a triangle test,
-    static constexpr double cost_group = 2.5;  // a group's or CSG shape's exact bounds test
-    static constexpr double worth = 0.5;       // a leaf's box must have at most this share of the enclosing box's area
+    double need = 2.0;        // expected saved visits a run's box must reach
+    double cost_quad = 1.0;   // visit costs in units of one T_CULL test: a leaf's own T_CULL record,
+    double cost_tri = 1.5;    // a triangle test,
+    double cost_group = 2.5;  // a group's or CSG shape's exact bounds test
+    double worth = 0.5;       // a leaf's box must have at most this share of the enclosing box's area
 
     const rt_scene_desc* d;
     bool no_cull;
@@ -2883,6 +2883,8 @@ std::vector<TRec> build_records(const rt_scene_desc* d, BoxFacts* facts = nullpt
     b.rec.assign(d->n_nodes + 1, -1);
     node_boxes(d, b.box, b.cone_below);
     b.reorder = !(getenv("RT_REORDER") && atoi(getenv("RT_REORDER")) == 0);  // RT_REORDER=0: diagnostic
+    if (const char* tune = getenv("RT_TUNE"))  // diagnostic: "need,cost_quad,cost_tri,cost_group,worth"
+        sscanf(tune, "%lf,%lf,%lf,%lf,%lf", &b.need, &b.cost_quad, &b.cost_tri, &b.cost_group, &b.worth);
     b.emit_children(0, d->n_nodes, INFINITY, false);
     if (facts) {
         for (const NodeBox& nb : b.box) {

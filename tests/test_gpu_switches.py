@@ -28,7 +28,7 @@ for name, (W, H) in (("default", (1024, 576)), ("glass", (320, 200)), ("csg", (2
 
 def render_hashes(env_extra):
     env = dict(os.environ)
-    for k in ("RT_NO_CULL", "RT_REORDER", "RT_TILE_ORDER", "RT_DIAG", "RT_SPLIT", "RT_PROBE"):
+    for k in ("RT_NO_CULL", "RT_REORDER", "RT_TILE_ORDER", "RT_DIAG", "RT_SPLIT", "RT_PROBE", "RT_TUNE"):
         env.pop(k, None)
     env.update(env_extra)
     out = subprocess.run([sys.executable, "-c", CHILD], env=env, capture_output=True, text=True, timeout=300)
@@ -41,5 +41,6 @@ def test_switches_do_not_change_a_pixel():
     assert len(base) == 5
     for env in ({"RT_NO_CULL": "1"}, {"RT_REORDER": "0"}, {"RT_TILE_ORDER": "0"}, {"RT_DIAG": "0"}, {"RT_SPLIT": "1"},
                 {"RT_SPLIT": "4", "RT_PROBE": "0"}, {"RT_SPLIT": "2", "RT_PROBE": "3"},
-                {"RT_NO_CULL": "1", "RT_REORDER": "0", "RT_TILE_ORDER": "0"}):
+                {"RT_NO_CULL": "1", "RT_REORDER": "0", "RT_TILE_ORDER": "0"}, {"RT_TUNE": "0.5,1,1,1,1.0"},
+                {"RT_TUNE": "6,1,1.5,1.2,0.3"}):
         assert render_hashes(env) == base, env
