@@ -440,6 +440,20 @@ struct Hit {
 // Lanes of the wavefront for which the predicate holds, straight from the comparison's lane mask
 // (the library's __ballot takes an int, which costs a select and a second comparison).
 DI unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// The same value, as far as the compiler can tell a new one: what is derived from it is computed where
+// it is used instead of once, far ahead, and kept (or spilled) until then.
+template <typename T>
+DI T opaque(T x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
+// The lane number, computed on the spot (two instructions that read no register), for code that runs
+// after a long loop which would otherwise keep it, or spill it, for that use alone.
+DI int fresh_lane() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
+}
 
 DI int wave_min(int v) {
 #pragma unroll
@@ -1485,7 +1499,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                                                  unsigned long long* __restrict__ counters,
                                                  unsigned long long* __restrict__ clear_counters) {
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    const int wave = RT_BLOCK_WAVES == 1 ? 0 : (int)(threadIdx.x >> 6);
     // The scene keeps two sets of ray counters; this launch clears the set the next launch will
     // use, which saves a memset (and its launch gap) per frame.
     {
@@ -1495,7 +1509,11 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     // A lane parks its finished pixel in LDS instead of carrying it through the rest of the
     // wavefront's rounds; the tile is written from there at the end.
     __shared__ double tile_lds[RT_BLOCK_WAVES][64 * 3];
-    double* const my_pixel = tile_lds[wave] + lane * 3;
+    // The slot's address is derived again from the lane number where it is used: computed once up here it
+    // (and the other lane-derived addresses of the epilogue) would be spilled across the bounce loop,
+    // 1.3 KB of scratch written and read back per wavefront.
+    auto pixel_slot = [&]() -> double* { return tile_lds[wave] + fresh_lane() * 3; };
+    double* my_pixel = pixel_slot();
     // What is only needed again after a shadow walk waits in LDS meanwhile ([value][lane]: no bank
     // conflicts), which keeps it out of the registers the walk needs: 127 -> 113 VGPRs at four
     // wavefronts per SIMD, and five fit.  6 KB per wavefront; 20 wavefronts fill a CU's 160 KB.
@@ -1790,6 +1808,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                 }
                 while (returning) {
                     if (sp == 0) {
+                        my_pixel = pixel_slot();
                         my_pixel[0] = value.x;
                         my_pixel[1] = value.y;
                         my_pixel[2] = value.z;
@@ -1848,6 +1867,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
                             frames[0].refl[2] = value.z;
                             job |= L_HOLDING;
                         } else {
+                            my_pixel = pixel_slot();
                             my_pixel[0] = value.x;
                             my_pixel[1] = value.y;
                             my_pixel[2] = value.z;
@@ -1983,22 +2003,27 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
 #endif
     }
 
+    // The frame is written once and not read again by this launch: the stores are marked non-temporal so
+    // that its lines do not push the wavefronts' recursion stacks out of L2.
+    typedef double dv2 __attribute__((ext_vector_type(2)));
     // ---- write the tile ------------------------------------------------------------------------
     // A tile row is 8 pixels = 192 contiguous bytes.  The pixels sit in LDS in lane order, so every
     // lane stores 16-byte pieces and each store instruction covers whole rows (three 8-byte
     // stores per lane with a 24-byte stride would write every line three times).
     __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0): LDS writes of this wave are done
     __builtin_amdgcn_wave_barrier();
+    const int lane_w = fresh_lane();  // see pixel_slot
+    my_pixel = pixel_slot();
     long long out_index;
     int rows = RT_TILE;    // rows of the tile this wavefront stores
     long long origin = 0;  // first pixel of the tile or strip in the output
     if (J.n_rays > 0) {
-        out_index = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-        origin = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+        out_index = (long long)blockIdx.x * blockDim.x + (wave * 64 + lane_w);
+        origin = (long long)blockIdx.x * blockDim.x + wave * 64;
     } else {
         int px, row_in_tile, lty;
-        lane_pixel(J, wave, lane, px, row_in_tile, lty, rows, origin);  // again: cheaper than keeping it in registers
-        out_index = origin + (long long)(lane >> 3) * J.width + (lane & 7);
+        lane_pixel(J, wave, lane_w, px, row_in_tile, lty, rows, origin);  // again: cheaper than keeping it in registers
+        out_index = origin + (long long)(lane_w >> 3) * J.width + (lane_w & 7);
     }
     // every pixel of the tile (or strip) is inside the frame: whole rows can be stored
     const unsigned long long all_lanes = rows >= RT_TILE ? ~0ull : ((1ull << (rows * 8)) - 1ull);
@@ -2010,15 +2035,15 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         unsigned char* const out8 = reinterpret_cast<unsigned char*>(out);
         const unsigned r = clamp_u8(my_pixel[0]), g = clamp_u8(my_pixel[1]), b = clamp_u8(my_pixel[2]);
         if (whole_tile) {
-            t8[lane * 3] = (unsigned char)r;
-            t8[lane * 3 + 1] = (unsigned char)g;
-            t8[lane * 3 + 2] = (unsigned char)b;
+            t8[lane_w * 3] = (unsigned char)r;
+            t8[lane_w * 3 + 1] = (unsigned char)g;
+            t8[lane_w * 3 + 2] = (unsigned char)b;
             __builtin_amdgcn_s_waitcnt(0xc07f);
             __builtin_amdgcn_wave_barrier();
-            if (lane < rows * 6) {
-                const int row = lane / 6, piece = lane % 6;
-                *reinterpret_cast<unsigned*>(out8 + (origin + (long long)row * J.width) * 3 + piece * 4) =
-                    tile8_lds[wave][lane];
+            if (lane_w < rows * 6) {
+                const int row = lane_w / 6, piece = lane_w % 6;
+                __builtin_nontemporal_store(tile8_lds[wave][lane_w],
+                                            reinterpret_cast<unsigned*>(out8 + (origin + (long long)row * J.width) * 3 + piece * 4));
             }
         } else if (valid) {
             out8[out_index * 3] = (unsigned char)r;
@@ -2027,21 +2052,24 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         }
     } else if (whole_tile) {
         const double* t = tile_lds[wave];
-        // rows of the tile are 8 pixels apart in the lane order, so the LDS image is already
+        // rows of the tile are 8 pixels apart in the lane_w order, so the LDS image is already
         // [row][192 bytes]; piece c (16 bytes) belongs to row c / 12, byte offset (c % 12) * 16
         const long long row_stride = (long long)J.width * 3;  // doubles
         const long long base = origin * 3;
         if (rows == RT_TILE) {
 #pragma unroll
-            for (int c = lane; c < RT_TILE * 12; c += 64) {
-                const int row = c / 12, piece = c % 12;
-                double2 v = *reinterpret_cast<const double2*>(t + row * 24 + piece * 2);
-                *reinterpret_cast<double2*>(out + base + row * row_stride + piece * 2) = v;
+            for (int k = 0; k < 2; ++k) {  // 96 pieces: every lane has one, the first 32 lanes a second one
+                const int c = lane_w + k * 64;
+                if (c < RT_TILE * 12) {
+                    const int row = c / 12, piece = c % 12;
+                    const dv2 v = *reinterpret_cast<const dv2*>(t + row * 24 + piece * 2);
+                    __builtin_nontemporal_store(v, reinterpret_cast<dv2*>(out + base + row * row_stride + piece * 2));
+                }
             }
-        } else if (lane < rows * 12) {  // a strip: at most four rows, 48 pieces
-            const int row = lane / 12, piece = lane % 12;
-            double2 v = *reinterpret_cast<const double2*>(t + row * 24 + piece * 2);
-            *reinterpret_cast<double2*>(out + base + row * row_stride + piece * 2) = v;
+        } else if (lane_w < rows * 12) {  // a strip: at most four rows, 48 pieces
+            const int row = lane_w / 12, piece = lane_w % 12;
+            const dv2 v = *reinterpret_cast<const dv2*>(t + row * 24 + piece * 2);
+            __builtin_nontemporal_store(v, reinterpret_cast<dv2*>(out + base + row * row_stride + piece * 2));
         }
     } else if (valid) {
         out[out_index * 3] = my_pixel[0];
@@ -2052,7 +2080,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     // that the 10^5 wavefronts of a frame do not serialise on four words.
     counters += 16 * ((blockIdx.x * (unsigned)RT_BLOCK_WAVES + (unsigned)wave) % COUNTER_SHARDS);
 #ifdef RT_PROFILE
-    if (lane == 0) {
+    if (lane_w == 0) {
         atomicAdd(&counters[4], __builtin_amdgcn_s_memtime() - prof_t0);
         atomicAdd(&counters[5], prof_closest);
         atomicAdd(&counters[6], prof_shadow);
@@ -2066,7 +2094,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
     }
 #endif
 #ifdef RT_PROFILE_MIX
-    if (lane == 0) {
+    if (lane_w == 0) {
         for (int k = 0; k < 8; ++k) atomicAdd(&counters[4 + k], mix[k]);
         atomicAdd(&counters[12], mix_rounds);
         atomicAdd(&counters[13], mix_handoffs);
@@ -2080,7 +2108,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         unsigned v = c[k];
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
-        if (lane == 0 && v) atomicAdd(&counters[k], (unsigned long long)v);
+        if (lane_w == 0 && v) atomicAdd(&counters[k], (unsigned long long)v);
     }
 }
 
