@@ -478,6 +478,9 @@ enum { MODE_CLOSEST = 0, MODE_CONTAINERS = 1, MODE_SHADOW = 2 };
 // XF: the scene has transformed groups or triangles (T_XFORM records); without them the ray never
 // changes space between records and the world-space copy is not kept.
 // CULL: the scene has T_CULL records.  CSGM: it has CSG shapes.
+#ifndef RT_WALK_PRIO
+#define RT_WALK_PRIO 2  // s_setprio level of a wavefront inside a traversal walk (0 elsewhere)
+#endif
 template <int MODE, bool XF, bool CULL, bool CSGM, bool GROW>
 DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h) {
     constexpr bool TRACK = MODE == MODE_CONTAINERS;
@@ -498,6 +501,11 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     h.n_cull = h.a_cull = h.n_group = h.a_group = h.n_leaf = h.a_leaf = h.n_leaf_idle = 0;
 #endif
     if (wave_ballot(active) == 0ull) return;
+    // A walk is a chain of dependent scalar fetches with a few vector instructions in between: a
+    // wavefront in it runs at a higher priority than the ones that shade, which have long runs of
+    // independent arithmetic to fill the gaps with (2 % on large frames, 6 % on 1920x1080; the
+    // other way round costs 4 %).
+    __builtin_amdgcn_s_setprio(RT_WALK_PRIO);
 
     int skip_until = active ? 0 : INT_MAX;
     const int n = S.n_trav;
@@ -999,6 +1007,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             i = wave_min(skip_until);  // INT_MAX when every lane is decided: the loop ends
         }
     }
+    __builtin_amdgcn_s_setprio(0);
     if (!TRACK) h.found = h.node >= 0;
 }
 
