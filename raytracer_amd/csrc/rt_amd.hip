@@ -478,6 +478,9 @@ enum { MODE_CLOSEST = 0, MODE_CONTAINERS = 1, MODE_SHADOW = 2 };
 // XF: the scene has transformed groups or triangles (T_XFORM records); without them the ray never
 // changes space between records and the world-space copy is not kept.
 // CULL: the scene has T_CULL records.  CSGM: it has CSG shapes.
+#ifndef RT_INNER_CULL
+#define RT_INNER_CULL (!CSGM)  // cull boxes in a loop of their own (see trace); the kernels for CSG scenes are 6 % slower with it
+#endif
 #ifndef RT_WALK_PRIO
 #define RT_WALK_PRIO 2  // s_setprio level of a wavefront inside a traversal walk (0 elsewhere)
 #endif
@@ -610,26 +613,79 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
 #ifdef RT_PROFILE
     h.visits = 0;
 #endif
-    while (i < n) {
-        i = __builtin_amdgcn_readfirstlane(i);
-#ifdef RT_PROFILE
-        ++h.visits;
-#endif
-        const RT_CONST TRec* rec = S.trav + i;
-        // Fetch the whole 128-byte record with one scalar-load round trip.  The empty asm
-        // statements make every field live here, so the loads are issued together instead of
-        // one dependent load per use.
-        const int kind = rec->kind;
-        const int skip = rec->skip;
-        const int ctx = rec->ctx;
-        const int rnode = rec->node;
-        const double r0 = rec->r0, r1 = rec->r1;
-        double q[12];
+    // The record at `i`, fetched whole with one scalar-load round trip (base + 32-bit byte offset: the
+    // loads take the offset in a register and no 64-bit address is computed per record).  The empty
+    // asm statements make every field live at once, so the loads are issued together instead of one
+    // dependent load per use.
+    int kind, skip, ctx, rnode;
+    double r0, r1;
+    double q[12];
+    auto fetch = [&]() {
+        static_assert(sizeof(TRec) == 128, "the record offset below is i * 128");
+        const RT_CONST TRec* rec = reinterpret_cast<const RT_CONST TRec*>(
+            reinterpret_cast<const RT_CONST char*>(S.trav) + ((unsigned)i << 7));
+        kind = rec->kind;
+        skip = rec->skip;
+        ctx = rec->ctx;
+        rnode = rec->node;
+        r0 = rec->r0;
+        r1 = rec->r1;
 #pragma unroll
         for (int k = 0; k < 12; ++k) q[k] = rec->p[k];
         asm volatile("" ::"s"(kind), "s"(skip), "s"(ctx), "s"(rnode), "s"(r0), "s"(r1));
         asm volatile("" ::"s"(q[0]), "s"(q[1]), "s"(q[2]), "s"(q[3]), "s"(q[4]), "s"(q[5]), "s"(q[6]), "s"(q[7]),
                      "s"(q[8]), "s"(q[9]), "s"(q[10]), "s"(q[11]));
+#ifdef RT_PROFILE
+        ++h.visits;
+#endif
+    };
+    // Padded box in front of a leaf or a run of siblings, tested in single precision (see slabs_f32):
+    // p[6..8] hold the planes as floats, p[9] the margin's two box-dependent factors.  Returns the next
+    // record: the one after the box's subtree when no lane needs it.
+    auto cull_box = [&]() -> int {
+        const bool act = i >= skip_until;
+#ifdef RT_PROFILE_MIX
+        ++h.n_cull;
+        h.a_cull += __builtin_popcountll(wave_ballot(act));
+#endif
+        float tmin, tmax;
+        slabs_f32<GROW>(q[6], q[7], q[8], box, tmin, tmax);
+        const f2 kk = __builtin_bit_cast(f2, q[9]);
+        const float G = __builtin_fmaf(kk.y, osq_ym, __builtin_fmaf(kk.x, ym, c_cull));
+        // (lane masks of the single comparisons, combined as scalars: a ballot of the combined
+        // condition would go through a vector register)
+        const bool c_miss = (tmin - tmax) > G;
+        bool keep = !c_miss;
+        unsigned long long drop = wave_ballot(c_miss);
+        if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
+            if (!TRACK) {
+                const bool c_behind = tmax < -G;  // only positive times count
+                keep = keep && !c_behind;
+                drop |= wave_ballot(c_behind);
+            }
+            const bool c_beyond = (tmin - G) > hlim;  // beyond the light or the nearest hit so far; container pass: > 0
+            keep = keep && !c_beyond;
+            drop |= wave_ballot(c_beyond);
+        }
+        if (act && !keep) skip_until = skip;
+        return ((wave_ballot(act) & ~drop) == 0ull) ? skip : i + 1;
+    };
+    while (i < n) {
+        i = __builtin_amdgcn_readfirstlane(i);
+        fetch();
+        if (CULL && RT_INNER_CULL) {
+            // Runs of cull boxes in the space the ray is in already (half of all records) go round a
+            // loop of their own: it has only wave-uniform branches, so its back edge is a plain jump
+            // and the hit state is not touched, where the big loop's body, which has divergent parts,
+            // is threaded through join blocks.  (Group boxes in this loop too, with or without their
+            // exact fallback, made every workload slower.)
+            while ((kind & 0xff) == T_CULL && (!XF || ctx == cur_ctx)) {
+                i = cull_box();
+                if (i >= n) break;
+                fetch();
+            }
+            if (i >= n) break;
+        }
         const int type = kind & 0xff;
         if (XF && ctx != cur_ctx) {
             co = wo;
@@ -654,35 +710,12 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
 #ifdef RT_PROFILE_MIX
         {
             const int lanes = __builtin_popcountll(wave_ballot(act));
-            if (type == T_CULL) { ++h.n_cull; h.a_cull += lanes; }
-            else if (type == RT_GROUP || type == T_CSG_BEGIN) { ++h.n_group; h.a_group += lanes; }
+            if (type == RT_GROUP || type == T_CSG_BEGIN) { ++h.n_group; h.a_group += lanes; }
             else if (type < T_XFORM) { ++h.n_leaf; h.a_leaf += lanes; if (lanes == 0) ++h.n_leaf_idle; }
         }
 #endif
-        if (CULL && type == T_CULL) {
-            // Padded box in front of a leaf or a run of siblings, tested in single precision (see
-            // slabs_f32): p[6..8] hold the planes as floats, p[9] the margin's two box-dependent factors.
-            float tmin, tmax;
-            slabs_f32<GROW>(q[6], q[7], q[8], box, tmin, tmax);
-            const f2 kk = __builtin_bit_cast(f2, q[9]);
-            const float G = __builtin_fmaf(kk.y, osq_ym, __builtin_fmaf(kk.x, ym, c_cull));
-            // (lane masks of the single comparisons, combined as scalars: a ballot of the combined
-            // condition would go through a vector register)
-            const bool c_miss = (tmin - tmax) > G;
-            bool keep = !c_miss;
-            unsigned long long drop = wave_ballot(c_miss);
-            if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
-                if (!TRACK) {
-                    const bool c_behind = tmax < -G;  // only positive times count
-                    keep = keep && !c_behind;
-                    drop |= wave_ballot(c_behind);
-                }
-                const bool c_beyond = (tmin - G) > hlim;  // beyond the light or the nearest hit so far; container pass: > 0
-                keep = keep && !c_beyond;
-                drop |= wave_ballot(c_beyond);
-            }
-            if (act && !keep) skip_until = skip;
-            i = ((wave_ballot(act) & ~drop) == 0ull) ? skip : i + 1;
+        if ((XF || !RT_INNER_CULL) && CULL && type == T_CULL) {  // (the first box in a transformed group's space; the others take the loop above)
+            i = cull_box();
             continue;
         }
         if (CSGM && type == T_CSG_END) {
@@ -3251,6 +3284,10 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             const double kappa = 2.0 * 1.4143e-5 * facts.drift_max * 1.001;
             s->dev.cube_kappa = round_up_f32(kappa);
             s->dev.ymin_limit = (float)(0.49 / kappa);
+        }
+        // the kernel addresses records by a 32-bit byte offset
+        if (recs.size() >= (size_t(1) << 25)) {
+            return cleanup(fail(RT_ERR_LIMIT, "more than 2^25 traversal records"));
         }
         s->build.n_records = (int32_t)recs.size();
         for (const TRec& r : recs)
