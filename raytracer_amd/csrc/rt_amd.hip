@@ -681,7 +681,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             // exact fallback, made every workload slower.)
             while ((kind & 0xff) == T_CULL && (!XF || ctx == cur_ctx)) {
                 i = cull_box();
-                if (i >= n) break;
+                if (__builtin_expect(i >= n, 0)) break;
                 fetch();
             }
             if (i >= n) break;
@@ -941,7 +941,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 }
                 case RT_CUBE: {  // cube.rs:77-98
                     double tmin, tmax;
-                    if (wave_ballot(!all_axes_finite(ld)) == 0ull)
+                    if (__builtin_expect(wave_ballot(!all_axes_finite(ld)) == 0ull, 1))
                         slabs_fast(lo, ld, reciprocal(ld), -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
                     else
                         slabs(lo, ld, -1.0, -1.0, -1.0, 1.0, 1.0, 1.0, tmin, tmax);
