@@ -2659,11 +2659,13 @@ void node_boxes(const rt_scene_desc* d, std::vector<NodeBox>& box, std::vector<c
 struct RecordBuilder {
     static constexpr int CLUSTER_MIN = 2;
     // Tuned on the default scene, a scene of loose quadrics and three divided meshes (870 k
-    // triangles the largest); the frame times move by a few percent over 1..4, 1..3, 1.5..4, 0.3..0.9.
+    // triangles the largest); the frame times move by a few percent over 1..4, 1..3, 1.5..5, 0.3..0.9.
+    // (A T_CULL test became cheaper relative to the others when runs of them got a loop of their own
+    // in the kernel: triangles at 2.5..5 instead of 1.5 took 3-5 % off the mesh frames.)
     double need = 2.0;        // expected saved visits a run's box must reach
     double cost_quad = 1.0;   // visit costs in units of one T_CULL test: a leaf's own T_CULL record,
-    double cost_tri = 1.5;    // a triangle test,
-    double cost_group = 2.5;  // a group's or CSG shape's exact bounds test
+    double cost_tri = 3.5;    // a triangle test,
+    double cost_group = 3.5;  // a group's or CSG shape's exact bounds test
     double worth = 0.5;       // a leaf's box must have at most this share of the enclosing box's area
 
     const rt_scene_desc* d;
