@@ -32,6 +32,8 @@ def spawn_ranks(argv, n_ranks, env_extra=None, timeout=None):
             "RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(n_ranks),
             "LOCAL_WORLD_SIZE": str(n_ranks), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port),
         })
+        # this image's host driver only supports dmabuf IPC handles, which RCCL needs between the ranks
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         env.update(env_extra or {})
         procs.append(subprocess.Popen([sys.executable] + list(argv), env=env,
                                       stdout=subprocess.PIPE if rank == 0 else sys.stderr,

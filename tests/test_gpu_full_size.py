@@ -85,9 +85,9 @@ def test_other_workloads_1920x1080(host, orc, name):
     assert np.array_equal(img8, quantise(img).astype(np.uint8))
 
 
-@pytest.mark.parametrize("name", ["glass", "dragon"])
+@pytest.mark.parametrize("name", ["glass", "dragon", "csg", "teapot", "smooth_teapot"])
 def test_glass_and_mesh_3840x2160(host, orc, name):
-    """The glass/pattern scene and the largest mesh at the 3840x2160 their timings are quoted at."""
+    """The glass/pattern scene, the CSG scene and the meshes at the 3840x2160 their timings are quoted at."""
     W, H = 3840, 2160
     mw, mc = scenes.WORKLOADS[name]
     img, st = host.render(mw(host), mc(host, W, H), stats=True)
