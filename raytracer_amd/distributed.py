@@ -73,6 +73,14 @@ class FrameGather:
                     req.wait()
         return self._place(local)
 
+    def _wide(self, t):
+        """Rows of clamped bytes seen as rows of 8-byte words, so that index_copy_ moves whole words:
+        placing the 3,780 peer rows of a 7680x4320 byte frame takes 0.03 ms that way and 0.135 ms byte
+        by byte (MI355X, tools/ubench/place_rows.py), on the GPU that is rendering the next frame."""
+        if t.dtype == torch.uint8 and (self.width * 3) % 8 == 0 and t.is_contiguous() and t.storage_offset() % 8 == 0:
+            return t.view(t.shape[0], self.width * 3).view(torch.int64)
+        return t
+
     def _collective(self, local):
         most = max(self.rows)
         if self.padded is None:
@@ -85,7 +93,10 @@ class FrameGather:
             return None
         for r in range(self.world_size):
             if self.rows[r] > 0:
-                self.frame.index_copy_(0, self.index[r], self.slots[r][: self.rows[r]])
+                src, dst = self._wide(self.slots[r][: self.rows[r]]), self._wide(self.frame)
+                if src.dtype != dst.dtype:
+                    src, dst = self.slots[r][: self.rows[r]], self.frame
+                dst.index_copy_(0, self.index[r], src)
         return self.frame
 
     def _staged(self, local):
@@ -102,10 +113,13 @@ class FrameGather:
     def _place(self, local):
         if self.rank != self.dst:
             return None
+        frame, own, others = self._wide(self.frame), self._wide(local), self._wide(self.staging)
+        if not (frame.dtype == own.dtype == others.dtype):
+            frame, own, others = self.frame, local, self.staging
         if self.rows[self.dst] > 0:
-            self.frame.index_copy_(0, self.index[self.dst], local)
+            frame.index_copy_(0, self.index[self.dst], own)
         if self.index_others is not None and self.index_others.numel() > 0:
-            self.frame.index_copy_(0, self.index_others, self.staging)
+            frame.index_copy_(0, self.index_others, others)
         return self.frame
 
 

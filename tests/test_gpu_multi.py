@@ -144,3 +144,24 @@ def test_same_world_on_two_devices(host):
     multi.render_device(cam, frame.data_ptr())
     assert np.array_equal(frame.cpu().numpy(), a)
     multi.close()
+
+
+@pytest.mark.parametrize("width", [64, 12, 7680])
+def test_rank_0_places_byte_rows_in_frame_order_on_the_device(host, width):
+    """What rank 0 of the one-process-per-GPU gather does with the rows it has received, on device
+    tensors: widths whose rows are whole 8-byte words are moved as words, others byte by byte."""
+    torch = pytest.importorskip("torch")
+    from raytracer_amd.distributed import FrameGather
+    dev = torch.device("cuda", 0)
+    H, ranks = 45 if width < 100 else 4320, 3
+    full = torch.randint(0, 256, (H, width, 3), dtype=torch.uint8, device=dev)
+    g = FrameGather(host, width, H, 0, ranks, dev, dtype=torch.uint8)
+    for r in range(1, ranks):
+        rows = torch.as_tensor(np.asarray(host.global_rows(H, r, ranks), dtype=np.int64), device=dev)
+        g.parts[r].copy_(full[rows])
+    own = torch.as_tensor(np.asarray(host.global_rows(H, 0, ranks), dtype=np.int64), device=dev)
+    for _ in range(2):  # both of the gather's frame buffers
+        g.frame = g.frames[g.calls % len(g.frames)]
+        g.calls += 1
+        g.frame.zero_()
+        assert torch.equal(g._place(full[own].contiguous()), full)
