@@ -36,6 +36,7 @@ class FrameGather:
         self.calls = 0
         self.parts = None
         self.index = None
+        self.recv_ops = None
         if rank == dst:
             self.frames = [torch.empty((height, width, 3), dtype=dtype, device=device) for _ in range(max(1, frames))]
             self.frame = self.frames[0]
@@ -64,8 +65,10 @@ class FrameGather:
             return self._collective(local)
         if self.world_size > 1:
             if self.rank == self.dst:
-                ops = [dist.P2POp(dist.irecv, self.parts[r], r) for r in range(self.world_size)
-                       if r != self.dst and self.rows[r] > 0]
+                if self.recv_ops is None:  # the same slices of the staging buffer every frame
+                    self.recv_ops = [dist.P2POp(dist.irecv, self.parts[r], r) for r in range(self.world_size)
+                                     if r != self.dst and self.rows[r] > 0]
+                ops = self.recv_ops
             else:
                 ops = [dist.P2POp(dist.isend, local, self.dst)] if self.rows[self.rank] > 0 else []
             if ops:
