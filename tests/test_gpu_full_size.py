@@ -99,6 +99,20 @@ def test_glass_and_mesh_3840x2160(host, orc, name):
         (cnt["rays_shadow"], cnt["rays_reflect"], cnt["rays_refract"])
 
 
+@pytest.mark.parametrize("name", ["default", "glass", "csg", "field", "teapot", "smooth_teapot", "dragon"])
+def test_ppm_of_every_configuration_1000x1000(host, orc, name):
+    """The parity gate as the metric words it, at the reference's own 1000x1000: the PPM text the
+    device renders and formats (rt_render_ppm) against Canvas::to_ppm of the oracle's frame.  The
+    gate allows 0.01 % of the pixels to differ by 1/255 per channel where ties flip; none do, so the
+    texts are compared byte for byte (header, values and the 70-column line breaks of canvas.rs:62-126)."""
+    W, H = 1000, 1000
+    mw, mc = scenes.WORKLOADS[name]
+    text = host.render_ppm(mw(host), mc(host, W, H))
+    ref = orc.render(mw(orc), mc(orc, W, H), threads=16)
+    assert text.startswith(b"P3\n1000 1000\n255\n")
+    assert text == orc.to_ppm(ref)
+
+
 def test_two_frames_in_flight(host):
     """Consecutive frames on two streams, each with its own scene handle and buffer (what bench.py does
     on several GPUs so that the next frame's wavefronts fill the GPU while this frame's longest ones
