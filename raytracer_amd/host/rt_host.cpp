@@ -188,6 +188,13 @@ struct BoundingBox {
         return o.min.x >= min.x && o.max.x <= max.x && o.min.y >= min.y && o.max.y <= max.y &&
                o.min.z >= min.z && o.max.z <= max.z;
     }
+    bool finite_and_ordered() const {
+        return std::isfinite(min.x) && std::isfinite(min.y) && std::isfinite(min.z) && std::isfinite(max.x) &&
+               std::isfinite(max.y) && std::isfinite(max.z) && min.x <= max.x && min.y <= max.y && min.z <= max.z;
+    }
+    BoundingBox plus_zero() const {  // what the identity matrix makes of the corners: -0 becomes +0
+        return {point(min.x + 0.0, min.y + 0.0, min.z + 0.0), point(max.x + 0.0, max.y + 0.0, max.z + 0.0)};
+    }
     BoundingBox transform(const Matrix& t) const {  // :59-78
         Tuple p[8] = {min,
                       point(min.x, min.y, max.z),
@@ -236,6 +243,11 @@ struct Phong {  // materials/phong.rs:10-19
 // ---- shapes ---------------------------------------------------------------------------------------
 struct Shape {
     int kind = RT_GROUP;
+    // Boxes are kept once computed (a leaf's never change, a group's until its children do), next to
+    // `kind` at the start of the object: `divide` asks every child for its box at every level, and
+    // with tens of thousands of triangles each object touched is a cache miss.
+    bool bounds_valid = false, ps_valid = false;
+    BoundingBox cached{}, ps_cached{};
     Matrix transform = Matrix::identity();
     std::shared_ptr<Phong> material;
     Shape* parent = nullptr;
@@ -245,8 +257,6 @@ struct Shape {
     Tuple p1{}, p2{}, p3{}, e1{}, e2{}, normal{}, n1{}, n2{}, n3{};
     std::vector<std::shared_ptr<Shape>> children;  // RT_CSG: left and right operand
     int op = 2;                                     // RT_CSG: 0 difference, 1 intersection, 2 union (csg.rs:27-31)
-    bool bounds_valid = false;
-    BoundingBox cached{};
 
     // Shape::includes (group.rs:172-182, csg.rs:177-179; leaves compare identity)
     bool includes(const Shape* other) const {
@@ -275,8 +285,12 @@ struct Shape {
                 return {point(-limit, minimum, -limit), point(limit, maximum, limit)};
             }
             case RT_TRIANGLE:
-            case RT_SMOOTH_TRIANGLE:  // triangle.rs:146-153
-                return BoundingBox::empty().add_point(p1).add_point(p2).add_point(p3);
+            case RT_SMOOTH_TRIANGLE:  // triangle.rs:146-153 (the corners never change: computed once)
+                if (!bounds_valid) {
+                    cached = BoundingBox::empty().add_point(p1).add_point(p2).add_point(p3);
+                    bounds_valid = true;
+                }
+                return cached;
             default:  // group.rs:196-208, 66-77; csg.rs:74-78 folds its two operands the same way
                 if (!bounds_valid) {
                     BoundingBox r = BoundingBox::empty();
@@ -287,17 +301,35 @@ struct Shape {
                 return cached;
         }
     }
-    BoundingBox parent_space_bounds_of() { return bounds().transform(transform); }  // shape.rs:103-105
-    void add_child(const std::shared_ptr<Shape>& c) {                              // group.rs:56-64
-        c->parent = this;
-        children.push_back(c);
-        bounds_valid = false;
+    // This group's children changed.  Only its own stored box is dropped, as in the reference
+    // (group.rs:56-64): a group further out that has been asked for its box before keeps that box.
+    void boxes_changed() { bounds_valid = ps_valid = false; }
+    BoundingBox parent_space_bounds_of() {  // shape.rs:103-105
+        if (ps_valid) return ps_cached;
+        ps_cached = parent_space_bounds_uncached();
+        ps_valid = true;
+        return ps_cached;
     }
-    void make_subgroup(const std::vector<std::shared_ptr<Shape>>& list) {  // group.rs:107-115
+    BoundingBox parent_space_bounds_uncached() {
+        BoundingBox b = bounds();
+        // The identity maps the eight corners of a finite, ordered box to themselves (1 * x + 0 * y +
+        // 0 * z + 0 * 1 is x, with +0 for either zero), so the box of the products is the box itself:
+        // `divide` asks for every child's box at every level, mostly of untransformed triangles.
+        if (b.finite_and_ordered() && transform.is_identity()) return b.plus_zero();
+        return b.transform(transform);
+    }
+    void add_child(std::shared_ptr<Shape> c) {  // group.rs:56-64
+        c->parent = this;
+        children.push_back(std::move(c));
+        boxes_changed();
+    }
+    void make_subgroup(std::vector<std::shared_ptr<Shape>>& list) {  // group.rs:107-115 (empties `list`)
         auto g = std::make_shared<Shape>();
         g->kind = RT_GROUP;
-        for (auto& c : list) g->add_child(c);
-        add_child(g);
+        g->children.reserve(list.size());
+        for (auto& c : list) g->add_child(std::move(c));
+        list.clear();
+        add_child(std::move(g));
     }
     void divide(size_t threshold) {  // group.rs:224-244, 79-105
         if (kind == RT_CSG) {        // csg.rs:216-219
@@ -313,13 +345,13 @@ struct Shape {
             for (auto& c : children) {
                 BoundingBox cb = c->parent_space_bounds_of();
                 if (lb.contains_box(cb))
-                    left.push_back(c);
+                    left.push_back(std::move(c));
                 else if (rb.contains_box(cb))
-                    right.push_back(c);
+                    right.push_back(std::move(c));
                 else
-                    keep.push_back(c);
+                    keep.push_back(std::move(c));
             }
-            children = keep;
+            children = std::move(keep);
             if (!left.empty()) make_subgroup(left);
             if (!right.empty()) make_subgroup(right);
         }

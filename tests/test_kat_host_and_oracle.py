@@ -146,6 +146,26 @@ def test_group_bounds(lib):  # group.rs:418-451
     close(mx, (4.0, 7.0, 4.5))
 
 
+def test_stored_group_bounds_are_dropped_by_the_group_itself_only(lib):
+    """Group::bounds stores the box it folds from its children (group.rs:196-208) and add_child drops
+    the stored box of the group it is called on, not of the groups around it (group.rs:56-64): after a
+    child is added to an inner group, the inner group's boxes follow, an outer group that has been
+    asked before keeps its box, and one that has not been asked sees the new child."""
+    M = lib.Matrix
+    outer, fresh, inner = lib.Group(), lib.Group(), lib.Group(M.translation(1, 0, 0))
+    inner.add_child(lib.Sphere())
+    outer.add_child(inner)
+    assert outer.bounds() == ((0, -1, -1), (2, 1, 1))
+    assert inner.parent_space_bounds_of() == ((0, -1, -1), (2, 1, 1))
+    inner.add_child(lib.Sphere(M.translation(0, 5, 0), lib.Phong.default(), True))
+    assert inner.bounds() == ((-1, -1, -1), (1, 6, 1))
+    assert inner.parent_space_bounds_of() == ((0, -1, -1), (2, 6, 1))
+    assert outer.bounds() == ((0, -1, -1), (2, 1, 1))
+    assert outer.parent_space_bounds_of() == ((0, -1, -1), (2, 1, 1))
+    fresh.add_child(inner)
+    assert fresh.bounds() == ((0, -1, -1), (2, 6, 1))
+
+
 def test_leaf_bounds(lib):  # sphere.rs:113, cube.rs:144, plane.rs:109, cylinder.rs:199, cone.rs:215, triangle.rs:146
     inf = math.inf
     assert lib.Sphere().bounds() == ((-1, -1, -1), (1, 1, 1))
