@@ -102,48 +102,131 @@ def cpu_baseline(name, W, H, budget_s=15.0):
     }
 
 
-def roofline_block(work, pmc, flops_share, kernel_ms, frame_bytes, W, H):
-    """flops_share: this launch's part of the frame's algorithmic operations."""
-    achieved = flops_share / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-    r = {
-        "bound": "valu-fp64",
-        "achieved": achieved,
-        "peak": FP64_VECTOR_PEAK_TFLOPS,
-        "unit": "TFLOP/s",
-        "frac": achieved / FP64_VECTOR_PEAK_TFLOPS,
-        "frac_is": "operations of the REFERENCE's algorithm for this frame (oracle count) per second / peak; the kernel "
-                   "skips work whose outcome is known (cull boxes, pruned subtrees), so on meshes this exceeds what the "
-                   "ALUs execute: see frac_executed",
-        "traffic": pmc["bytes_per_launch"] if pmc else None,
-        "peak_without_fma": FP64_VECTOR_PEAK_TFLOPS / 2,
-        "frac_without_fma": achieved / (FP64_VECTOR_PEAK_TFLOPS / 2),
-        "algorithmic_flops_per_launch": flops_share,
-        "kernel_ms": kernel_ms,
-    }
-    if pmc and pmc.get("executed_flops"):
-        ex = pmc["executed_flops"] / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        r["executed_flops"] = pmc["executed_flops"]  # 64 lanes x (f64 add + mul + 2 fma + transcendental) wave instructions
-        r["executed_tflops"] = ex
-        r["frac_executed"] = ex / FP64_VECTOR_PEAK_TFLOPS
-        r["valu_insts"] = pmc.get("valu_insts")
-        r["pmc_source"] = pmc.get("source")
-    # the secondary roof.  Algorithmic bytes: every group box tested (48 B + 8 B of links), every
-    # triangle tested (p1, e1, e2 = 72 B), the three vertex normals of every smooth triangle shaded
-    # (72 B) and the frame itself.
-    if work is not None:
-        scene_bytes = 56 * work.get("aabb_test", 0) + 72 * work.get("tri_test", 0) + 72 * work.get("smooth_hits", 0)
-        share = flops_share / float(work["flops"]) if work.get("flops") else 1.0
-        alg = scene_bytes * share + frame_bytes
-        r["hbm"] = {
-            "peak_gbs": HBM_PEAK_GBS,
-            "algorithmic_bytes_per_launch": alg,
-            "algorithmic_bytes_is": "56 x box tests + 72 x triangle tests + 72 x smooth-triangle hits of the reference's "
-                                    "algorithm + the frame store",
-            "frame_bytes": frame_bytes,
-            "algorithmic_gbs": alg / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0,
-            "measured_gbs": pmc["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 if pmc and kernel_ms > 0 else None,
-            "measured_frac_of_peak": pmc["bytes_per_launch"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if pmc and kernel_ms > 0 else None,
+N_SIMD = 1024                   # 256 CUs x 4 SIMDs
+PEAK_CLOCK_HZ = 2.4e9
+
+
+def table_bytes(host, scene):
+    """Device bytes of the scene's tables (all of them, and the traversal records alone)."""
+    from raytracer_amd import abi
+    info = abi.rt_build_info()
+    host.abi.rt_scene_build_info(scene, ctypes.byref(info))
+    return int(info.table_bytes), int(info.walk_bytes)
+
+
+def scaled_pmc(pmc, share):
+    """Counters of a whole-frame launch, scaled to a rank that renders `share` of the frame's tiles (the
+    tiles are dealt cyclically, so every rank gets the same mix)."""
+    if pmc is None or share == 1.0:
+        return pmc
+    out = dict(pmc)
+    for k in ("bytes_per_launch", "valu_busy_quads", "valu_insts", "valu_insts_in_2clock_classes", "executed_flops",
+              "smem_insts", "scalar_cache_requests", "scalar_cache_misses"):
+        if out.get(k) is not None:
+            out[k] = out[k] * share
+    out["source"] = "%s, scaled by %.4g (this rank's share of the frame)" % (pmc.get("source"), share)
+    return out
+
+
+def roofline_block(work, pmc, flops_share, kernel_ms, frame_bytes, W, H, tables=None, rays=None):
+    """The render kernel against the roofs of the machine.
+
+    flops_share: this launch's part of the frame's algorithmic operations.  The kernel has no dense
+    contraction (no MFMA) and its tables stay in the caches, so neither textbook roof is near; what it
+    can run into is the issue rate of the vector ALUs and, on scenes with long walks, the latency of
+    the chain of dependent scalar record fetches.  `bound` names the one that is nearest, `frac` is
+    the fraction of it (<= 1): live kernel time, counters of the rocprofv3 PMC passes of the same
+    command (profiles/pmc.json; tools/pmc_to_json.py documents units, corrections and the calibration).
+    """
+    sec = kernel_ms * 1e-3
+    fp64 = flops_share / sec / 1e12 if sec > 0 else 0.0
+    r = {"kernel_ms": kernel_ms, "traffic": pmc["bytes_per_launch"] if pmc else None}
+    cand = {}
+    if pmc and pmc.get("valu_busy_quads") and sec > 0:
+        busy = 4.0 * pmc["valu_busy_quads"]  # SIMD clocks spent issuing vector instructions, per launch
+        vi = {
+            "busy_simd_clocks_per_launch": busy,
+            "frac": busy / (N_SIMD * PEAK_CLOCK_HZ * sec),
+            "frac_is": "4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x 2.4 GHz x live kernel time); the counter charges "
+                       "2-clock 32-bit instructions a whole quad, so this is an upper bound; frac_min charges every instruction "
+                       "of the classes that hold them (INT32, ADD/MUL/FMA_F32) 2 clocks: a lower bound",
+            "frac_from_counters_alone": pmc.get("valu_issue_frac"),  # clocks from GRBM_GUI_ACTIVE of the same pass
+            "valu_insts_per_launch": pmc.get("valu_insts"),
+            "f64_share_of_valu_insts": pmc.get("f64_share_of_valu_insts"),
+            "mean_active_lanes": pmc.get("mean_active_lanes"),
         }
+        if pmc.get("valu_insts_in_2clock_classes") is not None:
+            vi["frac_min"] = (busy - 2.0 * pmc["valu_insts_in_2clock_classes"]) / (N_SIMD * PEAK_CLOCK_HZ * sec)
+        if rays:
+            vi["valu_insts_per_ray"] = pmc["valu_insts"] / rays if pmc.get("valu_insts") else None
+        r["valu_issue"] = vi
+        cand["valu-issue"] = (vi["frac"], busy / sec / 1e9, N_SIMD * PEAK_CLOCK_HZ / 1e9, "G SIMD-clocks/s")
+    if pmc and pmc.get("scalar_fetch_share") is not None:
+        sf = {
+            "share_of_wave_time_with_a_fetch_in_flight": pmc["scalar_fetch_share"],  # SQ_INST_CYCLES_SMEM / SQ_WAVE_CYCLES
+            "smem_insts_per_launch": pmc.get("smem_insts"),
+            "scalar_cache_requests_per_launch": pmc.get("scalar_cache_requests"),
+            "scalar_cache_misses_per_launch": pmc.get("scalar_cache_misses"),
+            "scalar_cache_requests_per_s": pmc["scalar_cache_requests"] / sec if pmc.get("scalar_cache_requests") and sec > 0 else None,
+            "mean_resident_waves_per_simd": pmc.get("mean_resident_waves_per_simd"),
+            "wait_any_share": pmc.get("wait_any_share"),
+        }
+        if work and work.get("walks"):
+            sf["oracle_walks_per_frame"] = work["walks"]
+        r["scalar_fetch"] = sf
+        cand["scalar-fetch-latency"] = (pmc["scalar_fetch_share"], pmc["scalar_fetch_share"], 1.0,
+                                        "share of resident-wavefront time with a dependent record fetch in flight")
+    # ---- FP64: operations of the reference's algorithm per second, and what the ALUs executed -----------
+    f = {
+        "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+        "algorithmic_flops_per_launch": flops_share,
+        "reference_work_rate": fp64,
+        "reference_work_rate_is": "f64 operations of the REFERENCE's algorithm for this frame (oracle count) per second.  The "
+                                  "kernel skips work whose outcome is known (cull boxes, pruned subtrees, f32 box tests), so "
+                                  "this is not ALU utilisation and may exceed the peak on meshes; `frac_executed` is utilisation",
+        "reference_work_rate_over_peak": fp64 / FP64_VECTOR_PEAK_TFLOPS,
+        "peak_without_fma": FP64_VECTOR_PEAK_TFLOPS / 2,
+        "reference_work_rate_over_peak_without_fma": fp64 / (FP64_VECTOR_PEAK_TFLOPS / 2),
+    }
+    if pmc and pmc.get("executed_flops") and sec > 0:
+        ex = pmc["executed_flops"] / sec / 1e12
+        f["executed_flops_per_launch"] = pmc["executed_flops"]  # 64 lanes x (f64 add + mul + 2 fma + transcendental) wave instructions
+        f["executed_tflops"] = ex
+        f["frac_executed"] = ex / FP64_VECTOR_PEAK_TFLOPS
+        cand["valu-fp64"] = (f["frac_executed"], ex, FP64_VECTOR_PEAK_TFLOPS, "TFLOP/s")
+    r["fp64"] = f
+    # ---- HBM: compulsory bytes (every table once, the frame once) against what moved ------------------------
+    if tables is not None:
+        compulsory = tables[0] + frame_bytes
+        h = {
+            "peak_gbs": HBM_PEAK_GBS,
+            "compulsory_bytes_per_launch": compulsory,
+            "compulsory_bytes_is": "every table of the scene read once (%d B, of which traversal records %d B) + the frame "
+                                   "stored once (%d B)" % (tables[0], tables[1], frame_bytes),
+            "compulsory_gbs": compulsory / sec / 1e9 if sec > 0 else 0.0,
+            "compulsory_frac_of_peak": compulsory / sec / 1e9 / HBM_PEAK_GBS if sec > 0 else 0.0,
+        }
+        if pmc and sec > 0:
+            h["measured_bytes_per_launch"] = pmc["bytes_per_launch"]  # 2 x FETCH_SIZE + WRITE_SIZE (gfx950 correction)
+            h["measured_gbs"] = pmc["bytes_per_launch"] / sec / 1e9
+            h["measured_frac_of_peak"] = h["measured_gbs"] / HBM_PEAK_GBS
+            h["measured_over_compulsory"] = pmc["bytes_per_launch"] / compulsory
+            cand["hbm"] = (h["measured_frac_of_peak"], h["measured_gbs"], HBM_PEAK_GBS, "GB/s")
+        r["hbm"] = h
+    # ---- the roof that is nearest ---------------------------------------------------------------------------
+    if cand:
+        name = max(cand, key=lambda k: cand[k][0])
+        r["bound"] = name
+        r["frac"], r["achieved"], r["peak"], r["unit"] = cand[name]
+        r["fractions"] = {k: v[0] for k, v in cand.items()}
+    else:
+        # no counters for this configuration (N > 1, or one that was never profiled): only the reference-work rate
+        r["bound"] = "valu-fp64"
+        r["achieved"], r["peak"], r["unit"] = fp64, FP64_VECTOR_PEAK_TFLOPS, "TFLOP/s"
+        r["frac"] = fp64 / FP64_VECTOR_PEAK_TFLOPS
+        r["frac_is"] = "no PMC counters for this configuration: reference-algorithm f64 operations per second over the peak"
+    if pmc:
+        r["pmc_source"] = pmc.get("source")
     return r
 
 
@@ -188,8 +271,22 @@ def single_gpu_4k(host, torch, dev, local_rank):
     out = {"workload": "default scene, 3840x2160, depth 5, f64 store, 1 frame in flight", "steps": 100,
            "ms_per_step": wall, "kernel_ms": kernel_ms, "rays_per_frame": rays, "value": rays / wall / 1e3, "unit": "Mrays/s"}
     if work:
-        out["roofline"] = roofline_block(work, load_pmc("default", W, H), float(work["flops"]), kernel_ms, W * H * 24, W, H)
+        tables = table_bytes(host, host.scene_handle(world, device=local_rank))
+        out["roofline"] = roofline_block(work, load_pmc("default", W, H), float(work["flops"]), kernel_ms, W * H * 24, W, H,
+                                         tables=tables, rays=rays)
     return out
+
+
+def single_gpu_8k_f64(host, torch, dev, local_rank):
+    """The headline frame with the f64 store (what render() returns, 796 MB) instead of the clamped bytes."""
+    from raytracer_amd import scenes
+    W, H = 7680, 4320
+    world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
+    wall, kernel_ms, rays, buf = timed_renders(host, world, cam, 30, 5, torch, dev, False, local_rank)
+    del buf
+    torch.cuda.empty_cache()
+    return {"workload": "default scene, 7680x4320, depth 5, f64 store, 1 frame in flight", "steps": 30,
+            "ms_per_step": wall, "kernel_ms": kernel_ms, "rays_per_frame": rays, "value": rays / wall / 1e3, "unit": "Mrays/s"}
 
 
 def e2e_block(host, torch, dev, local_rank, calls=12):
@@ -508,15 +605,23 @@ def main():
             "d2h_ms": d2h_ms,              # rank 0: the assembled frame to page-locked host memory
             "latency_frames": L,
             "kernel_ms_in_timed_region": kernel_ms_timed,
+            # `value` of round 1's record was measured at 3840x2160 with the f64 store; since round 2 the line is the
+            # 7680x4320 frame with the clamped-byte store (the multi-GPU configuration, the same at every N).  The
+            # old configuration is `single_gpu_4k`, the f64 store at this size `single_gpu_8k_f64`.
+            "metric_changed_from": "round 1: default scene 3840x2160, f64 store (now under single_gpu_4k)",
         }
         if work is not None:
             frame_bytes = rows * W * 3 * (1 if u8 else 8)
-            out["roofline"] = roofline_block(work, load_pmc(args.workload, W, H) if world_size == 1 else None,
-                                             float(work["flops"]) / world_size, kernel_ms, frame_bytes, W, H)
+            # (the PMC passes are whole-frame launches on one GPU; a rank of N renders 1/N of the tiles)
+            out["roofline"] = roofline_block(work, scaled_pmc(load_pmc(args.workload, W, H), 1.0 / world_size),
+                                             float(work["flops"]) / world_size, kernel_ms, frame_bytes, W, H,
+                                             tables=table_bytes(host, scene), rays=rays / world_size)
             out["roofline"]["oracle_rays_per_frame"] = work["rays"]
         if world_size == 1 and args.workload == "default" and not args.no_extras:
             host.reset()
             out["single_gpu_4k"] = single_gpu_4k(host, torch, dev, local_rank)
+            host.reset()
+            out["single_gpu_8k_f64"] = single_gpu_8k_f64(host, torch, dev, local_rank)
             host.reset()
             out["e2e"] = e2e_block(host, torch, dev, local_rank)
             host.reset()

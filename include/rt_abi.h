@@ -155,6 +155,9 @@ typedef struct rt_build_info {
     float records_ms;  /* laying the node table out as traversal and shading records (cull boxes, sorting) */
     float upload_ms;   /* device allocations and copies */
     int32_t n_nodes, n_records, n_cull_records;
+    int32_t reserved;
+    uint64_t walk_bytes;  /* device bytes of the traversal records (what a scene walk reads) */
+    uint64_t table_bytes; /* device bytes of every table of the scene, walk_bytes included */
 } rt_build_info;
 int rt_scene_build_info(const rt_scene* scene, rt_build_info* out);
 

@@ -92,7 +92,8 @@ class rt_stats(C.Structure):
 
 class rt_build_info(C.Structure):
     _fields_ = [("validate_ms", C.c_float), ("records_ms", C.c_float), ("upload_ms", C.c_float),
-                ("n_nodes", i32), ("n_records", i32), ("n_cull_records", i32)]
+                ("n_nodes", i32), ("n_records", i32), ("n_cull_records", i32), ("reserved", i32),
+                ("walk_bytes", C.c_uint64), ("table_bytes", C.c_uint64)]
 
 
 class rt_multi_stats(C.Structure):

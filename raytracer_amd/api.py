@@ -203,30 +203,42 @@ class HostApi(Api):
         return buf.raw[:n]
 
 
-class PinnedArray:
-    """Owns one rt_host_alloc block; `.array` is the numpy view.  Freed by close() or with the object."""
+class _PinnedBlock:
+    """One rt_host_alloc block, returned to the library when the last reference goes."""
 
-    def __init__(self, host, shape, dtype):
-        self.host = host
-        dtype = np.dtype(dtype)
-        n = int(np.prod(shape)) * dtype.itemsize
+    def __init__(self, host, n):
+        self.free = host.abi.rt_host_free
         self.ptr = host.abi.rt_host_alloc(max(n, 1))
         if not self.ptr:
             raise abi.RtError(abi.RT_ERR_HIP, (host.abi.rt_last_error() or b"").decode())
-        buf = (C.c_char * max(n, 1)).from_address(self.ptr)
-        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
-
-    def close(self):
-        if self.ptr:
-            self.array = None
-            self.host.abi.rt_host_free(self.ptr)
-            self.ptr = None
 
     def __del__(self):
         try:
-            self.close()
+            if self.ptr:
+                self.free(self.ptr)
+                self.ptr = None
         except Exception:
             pass
+
+
+class PinnedArray:
+    """`.array` is a numpy view of one rt_host_alloc block.  The block belongs to the buffer object every
+    view of it is based on (the array itself, slices, what Multi.render(out=...) returns), so it is only
+    freed once close() has been called (or this object is gone) AND no view is left: reading a view
+    after close() stays valid."""
+
+    def __init__(self, host, shape, dtype):
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape)) * dtype.itemsize
+        block = _PinnedBlock(host, n)
+        self.ptr = block.ptr
+        buf = (C.c_char * max(n, 1)).from_address(block.ptr)
+        buf._block = block  # numpy keeps `buf` as the base of every view
+        self.array = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+
+    def close(self):
+        self.array = None
+        self.ptr = None
 
 
 class Multi:

@@ -2317,6 +2317,7 @@ int upload(rt_scene* s, const T* src, size_t count, const RT_CONST T** dst) {
     HIP_TRY(hipMalloc(&p, bytes));
     s->allocations.push_back(p);
     if (count) HIP_TRY(hipMemcpy(p, src, count * sizeof(T), hipMemcpyHostToDevice));
+    s->build.table_bytes += count * sizeof(T);
     *dst = (const RT_CONST T*)p;
     return RT_OK;
 }
@@ -3296,6 +3297,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
             if ((r.kind & 0xff) == T_CULL) ++s->build.n_cull_records;
         if ((rc = upload(s, recs.data(), recs.size(), &s->dev.trav)) != RT_OK) return cleanup(rc);
         s->dev.n_trav = (int)recs.size();
+        s->build.walk_bytes = recs.size() * sizeof(TRec);
         bool cls[3] = {false, false, false};
         for (int i = 0; i < d->n_nodes; ++i)
             if (d->nodes[i].type != RT_GROUP && d->nodes[i].type != RT_CSG) {
@@ -3336,7 +3338,7 @@ int rt_scene_create(const rt_scene_desc* d, int device, rt_scene** out) {
         if (hipEventCreate(&s->ev_start[i]) != hipSuccess || hipEventCreate(&s->ev_stop[i]) != hipSuccess)
             return cleanup(fail(RT_ERR_HIP, "hipEventCreate failed"));
     }
-    HIP_TRY(hipDeviceSynchronize());
+    if (hipDeviceSynchronize() != hipSuccess) return cleanup(fail(RT_ERR_HIP, "hipDeviceSynchronize after the uploads failed"));
     s->build.validate_ms = (float)(t_validated - t_start);
     s->build.records_ms = (float)records_ms;
     s->build.upload_ms = (float)(rtdl::now_ms() - t_validated - records_ms);  // allocations, copies, events

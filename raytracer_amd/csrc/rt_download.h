@@ -199,10 +199,17 @@ public:
         }
         if (staged) *staged = true;
         const size_t chunk = SLOT_BYTES;
-        if (!slot_[0])
-            for (int i = 0; i < SLOTS; ++i)
-                if ((e = hipHostMalloc((void**)&slot_[i], chunk, hipHostMallocDefault)) != hipSuccess) return e;
+        for (int i = 0; i < SLOTS; ++i)  // (each slot on its own: an earlier call may have got only some of them)
+            if (!slot_[i] && (e = hipHostMalloc((void**)&slot_[i], chunk, hipHostMallocDefault)) != hipSuccess) {
+                slot_[i] = nullptr;
+                return e;
+            }
         const size_t n_chunks = (total + chunk - 1) / chunk;
+        // On an error nothing may stay in flight into the slots: the next call reuses them.
+        auto drained = [&](hipError_t err) {
+            (void)hipStreamSynchronize(stream_);
+            return err;
+        };
         auto place = [&](size_t c) -> hipError_t {
             const int s = (int)(c % SLOTS);
             hipError_t pe = hipEventSynchronize(ev_[s]);
@@ -212,14 +219,14 @@ public:
             return hipSuccess;
         };
         for (size_t c = 0; c < n_chunks; ++c) {
-            if (c >= (size_t)SLOTS && (e = place(c - SLOTS)) != hipSuccess) return e;  // frees the slot
+            if (c >= (size_t)SLOTS && (e = place(c - SLOTS)) != hipSuccess) return drained(e);  // frees the slot
             const int s = (int)(c % SLOTS);
             const size_t off = c * chunk, n = std::min(chunk, total - off);
-            if ((e = hipMemcpyAsync(slot_[s], d_src + off, n, hipMemcpyDeviceToHost, stream_)) != hipSuccess) return e;
-            if ((e = hipEventRecord(ev_[s], stream_)) != hipSuccess) return e;
+            if ((e = hipMemcpyAsync(slot_[s], d_src + off, n, hipMemcpyDeviceToHost, stream_)) != hipSuccess) return drained(e);
+            if ((e = hipEventRecord(ev_[s], stream_)) != hipSuccess) return drained(e);
         }
         for (size_t c = n_chunks > (size_t)SLOTS ? n_chunks - SLOTS : 0; c < n_chunks; ++c)
-            if ((e = place(c)) != hipSuccess) return e;
+            if ((e = place(c)) != hipSuccess) return drained(e);
         return hipSuccess;
     }
 

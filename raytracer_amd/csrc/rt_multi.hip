@@ -43,21 +43,29 @@ int mfail(int code, const std::string& msg) {
 constexpr int MAX_RANKS = 64;
 struct GatherArgs {
     const uint32_t* src[MAX_RANKS];  // every rank's compact buffer, as seen from rank 0's GPU
-    unsigned long long words[MAX_RANKS];  // its length in 4-byte words
+    unsigned long long bytes[MAX_RANKS];  // its length
 };
 
 // Frame assembly on rank 0's GPU: word w of rank r's compact buffer lies in that rank's tile
 // k = w / tile_words and goes to frame tile k * n + r.  blockIdx.y is the rank, so one launch pulls
-// from every peer at once.  Consecutive lanes read and write consecutive words.
+// from every peer at once.  Consecutive lanes read and write consecutive words.  A full tile is a
+// whole number of words (8 rows), but a byte frame's short last tile need not be: the one to three
+// bytes beyond the last whole word of the rank that owns it are copied one by one.
 __global__ void __launch_bounds__(256) gather_tiles_kernel(GatherArgs a, int n_ranks, unsigned long long tile_words,
                                                            uint32_t* __restrict__ frame) {
     const int r = blockIdx.y;
-    const unsigned long long total = a.words[r];
+    const unsigned long long total = a.bytes[r] / 4;
     const uint32_t* __restrict__ src = a.src[r];
     for (unsigned long long w = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; w < total;
          w += (unsigned long long)gridDim.x * blockDim.x) {
         const unsigned long long k = w / tile_words, within = w - k * tile_words;
         frame[(k * (unsigned long long)n_ranks + (unsigned long long)r) * tile_words + within] = src[w];
+    }
+    const unsigned long long tail = total * 4 + threadIdx.x;
+    if (blockIdx.x == 0 && threadIdx.x < 4 && tail < a.bytes[r]) {
+        const unsigned long long tile_bytes = tile_words * 4, k = tail / tile_bytes, within = tail - k * tile_bytes;
+        reinterpret_cast<uint8_t*>(frame)[(k * (unsigned long long)n_ranks + (unsigned long long)r) * tile_bytes + within] =
+            reinterpret_cast<const uint8_t*>(src)[tail];
     }
 }
 
@@ -315,7 +323,7 @@ int rt_render_multi_device(rt_multi* m, const rt_camera* cam, int32_t max_depth,
             src = m->d_stage[r];
         }
         args.src[r] = static_cast<const uint32_t*>(src);
-        args.words[r] = f.rank_bytes[r] / 4;
+        args.bytes[r] = f.rank_bytes[r];
     }
     MHIP(hipEventRecord(m->g0, s0));
     size_t most = 0;

@@ -193,6 +193,9 @@ pub struct rt_build_info {
     pub n_nodes: i32,
     pub n_records: i32,
     pub n_cull_records: i32,
+    pub reserved: i32,
+    pub walk_bytes: u64,
+    pub table_bytes: u64,
 }
 
 #[repr(C)]

@@ -1,4 +1,4 @@
-"""The multi-GPU frame assembly (raytracer_amd/distributed.py) on CPU: two and three gloo ranks each
+"""The multi-GPU frame assembly (raytracer_amd/distributed.py) on CPU: two, three and eight gloo ranks each
 produce their cyclic row tiles in compact order (the oracle stands in for the GPU renderer here) and
 rank 0 must reassemble exactly the single-process frame."""
 import os
@@ -49,7 +49,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world_size,size", [(2, (40, 37)), (3, (24, 50))])
+@pytest.mark.parametrize("world_size,size", [(2, (40, 37)), (3, (24, 50)), (8, (16, 70))])
 def test_gather_reassembles_frame(tmp_path, world_size, size):
     W, H = size
     out = str(tmp_path / "frames.npy")
@@ -93,8 +93,10 @@ def _worker_u8(rank, world_size, port, W, H, out_path, mode="p2p"):
         dist.destroy_process_group()
 
 
+# (8 ranks: the size of the machine the scaling run uses; 8-row tiles of a 67-row frame leave rank 0 with
+# two tiles, ranks 1..7 with one and the last of them short; 13 rows leave six ranks with nothing)
 @pytest.mark.parametrize("mode", ["p2p", "collective"])
-@pytest.mark.parametrize("world_size,size", [(2, (16, 37)), (3, (12, 50))])
+@pytest.mark.parametrize("world_size,size", [(2, (16, 37)), (3, (12, 50)), (8, (12, 67)), (8, (9, 13))])
 def test_overlapped_byte_gather(tmp_path, world_size, size, mode):
     W, H = size
     out = str(tmp_path / "frames.npy")
@@ -105,7 +107,7 @@ def test_overlapped_byte_gather(tmp_path, world_size, size, mode):
         assert np.array_equal(frames[k], ((yy * 7 + xx * 3 + cc * 11 + k * 5) % 256).astype(np.uint8))
 
 
-@pytest.mark.parametrize("world_size", [2, 3])
+@pytest.mark.parametrize("world_size", [2, 3, 8])
 def test_spawned_ranks_assemble_a_frame(world_size):
     """bench.py --gpus N without a launcher starts its own ranks with raytracer_amd.launch.spawn_ranks:
     fresh interpreters that find RANK / WORLD_SIZE / MASTER_* in their environment.  Here the ranks

@@ -57,16 +57,21 @@ def test_ranks_sharing_the_gpu_assemble_the_same_frame(host, ranks, size):
 @pytest.mark.parametrize("u8", [False, True])
 def test_frame_assembled_on_rank_0s_gpu(host, u8):
     torch = pytest.importorskip("torch")
-    W, H = 1000, 517   # W * 3 bytes * 8 rows is a multiple of 4; the last tile is short
-    world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
-    want = host.render_u8(world, cam) if u8 else host.render(world, cam)
-    for ranks in (1, 3):
-        multi = host.multi(world, ranks, devices=[0] * ranks)
-        frame = torch.zeros((H, W, 3), dtype=torch.uint8 if u8 else torch.float64, device="cuda:0")
-        st = multi.render_device(cam, frame.data_ptr(), u8=u8)
-        assert np.array_equal(frame.cpu().numpy(), want)
-        assert st.rays_primary == W * H and st.exchange_ms >= 0
-        multi.close()
+    # the last tile is short; at 1003x517 the byte frame's last tile (and the whole frame) is not a
+    # whole number of 4-byte words, so the rank that owns it ends on one to three single bytes
+    for W, H in ((1000, 517), (1003, 517)):
+        world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
+        want = host.render_u8(world, cam) if u8 else host.render(world, cam)
+        for ranks in (1, 3):
+            multi = host.multi(world, ranks, devices=[0] * ranks)
+            frame = torch.zeros((H, W, 3), dtype=torch.uint8 if u8 else torch.float64, device="cuda:0")
+            guard = torch.zeros(64, dtype=torch.uint8, device="cuda:0")  # (a neighbour that must stay untouched)
+            st = multi.render_device(cam, frame.data_ptr(), u8=u8)
+            assert np.array_equal(frame.cpu().numpy(), want)
+            assert not guard.any()
+            assert st.rays_primary == W * H and st.exchange_ms >= 0
+            multi.close()
+        host.reset()
 
 
 def test_large_frame_through_the_staging_ring_and_straight_to_pinned_memory(host):

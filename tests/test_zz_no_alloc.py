@@ -41,6 +41,21 @@ def test_static_scratch_render_equals_render_device(host, name):
         assert np.isfinite(want).all()
         assert np.array_equal(got, want), (name, W, H)
         assert got_rays == want_rays and got_rays[0] == W * H
+    # It allocates nothing: after a warm-up call, the device's free memory (as the driver reports it, so
+    # allocations by any library count) is the same before and after a run of calls, at both sizes.
+    prm = abi.rt_params(5, 0, 1, 0)
+    cams = [host.camera_block(mc(host, W, H)) for W, H in ((1003, 517), (1920, 1080))]
+    big = torch.empty((1080, 1920, 3), dtype=torch.float64, device=dev)
+    for c in cams:
+        assert lib.rt_render_device_static(scene, C.byref(c), C.byref(prm), C.c_void_p(big.data_ptr()), C.c_void_p(0)) == 0
+    torch.cuda.synchronize()
+    free_before, _ = torch.cuda.mem_get_info(dev)
+    for _ in range(3):
+        for c in cams:
+            assert lib.rt_render_device_static(scene, C.byref(c), C.byref(prm), C.c_void_p(big.data_ptr()), C.c_void_p(0)) == 0
+    torch.cuda.synchronize()
+    free_after, _ = torch.cuda.mem_get_info(dev)
+    assert free_after == free_before, (free_before, free_after)
     # the plain entry point still works after the static one, and agrees with itself
     again, _ = _render(host, lib.rt_render_device, scene, cam, buf, torch)
     assert np.array_equal(again, want)

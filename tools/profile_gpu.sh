@@ -14,9 +14,10 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/t
 PMC_BENCH="python $ROOT/bench.py --steps 2 --warmup 1 --no-extras $*"
 i=0
 for counters in \
-  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_ANY" \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_WAIT_ANY GRBM_GUI_ACTIVE" \
   "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_VMEM SQ_WAIT_INST_ANY SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_SCA" \
-  "GRBM_GUI_ACTIVE" \
+  "SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INST_CYCLES_SMEM" \
+  "SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_INSTS_SMEM_NORM SQ_ACTIVE_INST_VMEM" \
   "FETCH_SIZE" \
   "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum" ; do

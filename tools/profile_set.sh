@@ -15,7 +15,7 @@ for cfg in "$@"; do
   bash $ROOT/tools/profile_gpu.sh $tag --workload $w --width $W --height $H --store $store
   cp $ROOT/gpurun_out/$tag/trace/t_kernel_stats.csv $OUTDIR/kernel_stats_${w}_${size}.csv
   : > $OUTDIR/pmc_${w}_${size}.txt
-  for i in 1 2 3 4 5 6; do
+  for i in 1 2 3 4 5 6 7; do
     python $ROOT/tools/pmc_summary.py $ROOT/gpurun_out/$tag/pmc_$i/p_counter_collection.csv >> $OUTDIR/pmc_${w}_${size}.txt
   done
   echo "profiled $cfg"
