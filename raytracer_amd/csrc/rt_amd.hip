@@ -3091,7 +3091,8 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
     job.extra_blocks = 0;
     bool share = false;
     const bool grow = s->dev.cube_kappa != 0.0f;
-    if (job.tile_order && s->any_transparent && !s->any_csg) {
+    static const bool csg_share = !(getenv("RT_CSG_SHARE") && atoi(getenv("RT_CSG_SHARE")) == 0);  // diagnostic switch
+    if (job.tile_order && s->any_transparent && (!s->any_csg || csg_share)) {
         static const int split_env = getenv("RT_SPLIT") ? atoi(getenv("RT_SPLIT")) : 0;
         // measured on the default scene: 8,100 tiles 0.42 -> 0.25 ms with four strips, 32,400 tiles
         // 0.47 -> 0.35 ms with two, 64,800 tiles (an eighth of 7680x4320) 0.47 -> 0.49 ms, and at 129,600
@@ -3151,7 +3152,10 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
             kernel = growing[(s->any_transparent ? 2 : 0) | (s->any_xform ? 1 : 0)];
             if (share) kernel = s->any_xform ? rt_kernel<true, true, true, false, true, true> : rt_kernel<true, false, true, false, true, true>;
         }
-        if (s->any_csg) kernel = s->any_transparent ? rt_kernel<true, true, true, true, false, true> : rt_kernel<false, true, true, true, false, true>;
+        if (s->any_csg) {
+            kernel = s->any_transparent ? rt_kernel<true, true, true, true, false, true> : rt_kernel<false, true, true, true, false, true>;
+            if (share) kernel = rt_kernel<true, true, true, true, true, true>;
+        }
         hipLaunchKernelGGL(kernel, dim3(blocks), dim3(RT_BLOCK), 0, stream, s->dev, job, d_out, mine,
                            clears_other ? other : nullptr);
         HIP_TRY(hipGetLastError());
