@@ -128,7 +128,16 @@ def scaled_pmc(pmc, share):
     return out
 
 
-def roofline_block(work, pmc, flops_share, kernel_ms, frame_bytes, W, H, tables=None, rays=None):
+FETCH_CLOCKS = 235  # dependent 128-byte scalar fetch, 20 wavefronts per CU (tools/ubench/smem_latency, profiles/r3/issue_calib.txt)
+
+
+def load_walks(workload, W, H):
+    """Walks and records visited of one frame, from the -DRT_PROFILE build (tools/phase_set.sh -> profiles/walks.json)."""
+    table = load_json("profiles", "walks.json") or {}
+    return table.get("%s_%dx%d" % (workload, W, H))
+
+
+def roofline_block(work, pmc, flops_share, kernel_ms, frame_bytes, W, H, tables=None, rays=None, walks=None):
     """The render kernel against the roofs of the machine.
 
     flops_share: this launch's part of the frame's algorithmic operations.  The kernel has no dense
@@ -148,8 +157,9 @@ def roofline_block(work, pmc, flops_share, kernel_ms, frame_bytes, W, H, tables=
             "busy_simd_clocks_per_launch": busy,
             "frac": busy / (N_SIMD * PEAK_CLOCK_HZ * sec),
             "frac_is": "4 x SQ_ACTIVE_INST_VALU (quad-cycles) / (1024 SIMDs x 2.4 GHz x live kernel time); the counter charges "
-                       "2-clock 32-bit instructions a whole quad, so this is an upper bound; frac_min charges every instruction "
-                       "of the classes that hold them (INT32, ADD/MUL/FMA_F32) 2 clocks: a lower bound",
+                       "2-clock 32-bit instructions (v_mov, v_and, f32 add / multiply-add) a whole quad, so this is an upper "
+                       "bound; frac_min charges 2 clocks for every instruction outside the classes known to take 4 or more "
+                       "(F64, CVT, INT32, INT64, TRANS_F32): a lower bound (compares, selects, min / max are outside them too)",
             "frac_from_counters_alone": pmc.get("valu_issue_frac"),  # clocks from GRBM_GUI_ACTIVE of the same pass
             "valu_insts_per_launch": pmc.get("valu_insts"),
             "f64_share_of_valu_insts": pmc.get("f64_share_of_valu_insts"),
@@ -158,24 +168,36 @@ def roofline_block(work, pmc, flops_share, kernel_ms, frame_bytes, W, H, tables=
         if pmc.get("valu_insts_in_2clock_classes") is not None:
             vi["frac_min"] = (busy - 2.0 * pmc["valu_insts_in_2clock_classes"]) / (N_SIMD * PEAK_CLOCK_HZ * sec)
         if rays:
-            vi["valu_insts_per_ray"] = pmc["valu_insts"] / rays if pmc.get("valu_insts") else None
+            vi["valu_insts_per_ray"] = 64.0 * pmc["valu_insts"] / rays if pmc.get("valu_insts") else None  # lane instructions
         r["valu_issue"] = vi
         cand["valu-issue"] = (vi["frac"], busy / sec / 1e9, N_SIMD * PEAK_CLOCK_HZ / 1e9, "G SIMD-clocks/s")
-    if pmc and pmc.get("scalar_fetch_share") is not None:
+    # ---- the walk's chain of dependent record fetches (scalar loads through the scalar cache) ---------------
+    if pmc and pmc.get("scalar_cache_requests") and sec > 0:
         sf = {
-            "share_of_wave_time_with_a_fetch_in_flight": pmc["scalar_fetch_share"],  # SQ_INST_CYCLES_SMEM / SQ_WAVE_CYCLES
             "smem_insts_per_launch": pmc.get("smem_insts"),
-            "scalar_cache_requests_per_launch": pmc.get("scalar_cache_requests"),
-            "scalar_cache_misses_per_launch": pmc.get("scalar_cache_misses"),
-            "scalar_cache_requests_per_s": pmc["scalar_cache_requests"] / sec if pmc.get("scalar_cache_requests") and sec > 0 else None,
+            "scalar_cache_requests_per_launch": pmc["scalar_cache_requests"],
+            "scalar_cache_requests_per_s": pmc["scalar_cache_requests"] / sec,
+            "scalar_cache_miss_rate": (pmc.get("scalar_cache_misses") or 0.0) / pmc["scalar_cache_requests"],
+            "salu_issue_frac": 4.0 * pmc["salu_insts"] / (N_SIMD * PEAK_CLOCK_HZ * sec) if pmc.get("salu_insts") else None,
             "mean_resident_waves_per_simd": pmc.get("mean_resident_waves_per_simd"),
-            "wait_any_share": pmc.get("wait_any_share"),
         }
-        if work and work.get("walks"):
-            sf["oracle_walks_per_frame"] = work["walks"]
+        if walks:
+            # from the -DRT_PROFILE build of the same frame (profiles/walks.json): every record costs one dependent
+            # fetch, 235 clocks on a busy CU when it hits the scalar cache (tools/ubench/smem_latency)
+            per_wave = walks["records_visited"] / walks["waves"]
+            sf.update({
+                "walks_per_launch": walks["walks"], "records_visited_per_launch": walks["records_visited"],
+                "records_per_walk": walks["records_per_walk"],
+                "fetch_chain_clocks_per_wave": per_wave * FETCH_CLOCKS,
+                "mean_wave_clocks": walks["mean_wave_clocks"],
+                "fetch_chain_share_of_wave_time": per_wave * FETCH_CLOCKS / walks["mean_wave_clocks"],
+                "fetch_chain_share_is": "records visited per wavefront x %d clocks (a dependent 128-byte scalar fetch that hits, on a "
+                                        "busy CU) / mean wavefront lifetime; a lower bound when fetches miss the scalar cache" % FETCH_CLOCKS,
+                "time_share_of_walks": walks["share"]["nearest_hit_walks"] + walks["share"]["shadow_walks"],
+            })
+            cand["scalar-fetch-chain"] = (sf["fetch_chain_share_of_wave_time"], per_wave * FETCH_CLOCKS, walks["mean_wave_clocks"],
+                                          "clocks per wavefront")
         r["scalar_fetch"] = sf
-        cand["scalar-fetch-latency"] = (pmc["scalar_fetch_share"], pmc["scalar_fetch_share"], 1.0,
-                                        "share of resident-wavefront time with a dependent record fetch in flight")
     # ---- FP64: operations of the reference's algorithm per second, and what the ALUs executed -----------
     f = {
         "peak": FP64_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -273,7 +295,7 @@ def single_gpu_4k(host, torch, dev, local_rank):
     if work:
         tables = table_bytes(host, host.scene_handle(world, device=local_rank))
         out["roofline"] = roofline_block(work, load_pmc("default", W, H), float(work["flops"]), kernel_ms, W * H * 24, W, H,
-                                         tables=tables, rays=rays)
+                                         tables=tables, rays=rays, walks=load_walks("default", W, H))
     return out
 
 
@@ -615,7 +637,8 @@ def main():
             # (the PMC passes are whole-frame launches on one GPU; a rank of N renders 1/N of the tiles)
             out["roofline"] = roofline_block(work, scaled_pmc(load_pmc(args.workload, W, H), 1.0 / world_size),
                                              float(work["flops"]) / world_size, kernel_ms, frame_bytes, W, H,
-                                             tables=table_bytes(host, scene), rays=rays / world_size)
+                                             tables=table_bytes(host, scene), rays=rays / world_size,
+                                             walks=load_walks(args.workload, W, H) if world_size == 1 else None)
             out["roofline"]["oracle_rays_per_frame"] = work["rays"]
         if world_size == 1 and args.workload == "default" and not args.no_extras:
             host.reset()
@@ -635,7 +658,8 @@ def main():
 
 
 def single_process(args, host, make_world, make_camera, W, H):
-    """N GPUs from one process: rt_multi_create + rt_render_multi(_u8) into page-locked host memory."""
+    """N GPUs from one process: rt_multi_create + rt_render_multi(_u8) into page-locked host memory.  Prints the
+    same keys as the process-per-GPU line, so that a scaling run of either form reads like the other."""
     import numpy as np
     n = args.gpus
     world, cam = make_world(host), make_camera(host, W, H)
@@ -652,18 +676,44 @@ def single_process(args, host, make_world, make_camera, W, H):
     elapsed = time.perf_counter() - t0
     rays = st.total_rays()
     mean = lambda k: sum(p[k] for p in parts) / len(parts)
-    print(json.dumps({
+    # every call is one frame at a time already (the call returns when the frame is in host memory)
+    L = max(2, min(args.steps, 30))
+    lat = []
+    for _ in range(L):
+        t = time.perf_counter()
+        _, st = multi.render(cam, max_depth=args.max_depth, out=out_arr.array, u8=u8, stats=True)
+        lat.append(((time.perf_counter() - t) * 1e3, st.kernel_ms, st.exchange_ms))
+    latency_ms, kernel_ms, download_ms = (sum(p[k] for p in lat) / len(lat) for k in range(3))
+    out = {
         "metric": "Mrays/s (primary+secondary), %s scene %dx%d" % (args.workload, W, H),
         "value": rays * args.steps / elapsed / 1e6, "unit": "Mrays/s", "n_gpus": n, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": "%s scene, %dx%d, depth %d, %s frame to page-locked HOST memory" % (
-                       args.workload, W, H, args.max_depth, "clamped u8" if u8 else "f64"),
+        "config": {"workload": "%s scene%s, %dx%d, depth %d, %s frame to page-locked HOST memory" % (
+                       args.workload, " (src/lib.rs build_world)" if args.workload == "default" else " (raytracer_amd/scenes.py)",
+                       W, H, args.max_depth, "clamped u8" if u8 else "f64"),
                    "rays_per_frame": int(rays),
                    "partition": "cyclic 8-row tiles over %d GPU(s) of ONE process (rt_render_multi%s): every GPU copies its "
-                                "tiles over its own PCIe link" % (n, "_u8" if u8 else "")},
-        "kernel_ms": mean(0), "download_ms": mean(1), "call_ms": mean(2),
-    }))
+                                "tiles over its own PCIe link, no exchange between GPUs" % (n, "_u8" if u8 else ""),
+                   "frames_in_flight": 1},
+        "frame_latency_ms": latency_ms,   # one call: render on every GPU + the frame in host memory
+        "kernel_ms": kernel_ms,           # longest render launch over the GPUs (HIP events)
+        "gather_ms": 0.0,                 # nothing is gathered on a GPU in this form
+        "download_ms": download_ms,       # from the end of the longest render to the last byte in host memory
+        "d2h_ms": download_ms,
+        "latency_frames": L,
+        "kernel_ms_in_timed_region": mean(0), "download_ms_in_timed_region": mean(1), "call_ms": mean(2),
+    }
+    work = load_work(args.workload, W, H) if args.max_depth == 5 else None
+    if work is not None:
+        rows = host.local_rows(H, 0, n)
+        frame_bytes = rows * W * 3 * (1 if u8 else 8)
+        tables = table_bytes(host, host.scene_handle(world, device=0))
+        out["roofline"] = roofline_block(work, scaled_pmc(load_pmc(args.workload, W, H), 1.0 / n), float(work["flops"]) / n,
+                                         kernel_ms, frame_bytes, W, H, tables=tables, rays=rays / n,
+                                         walks=load_walks(args.workload, W, H) if n == 1 else None)
+        out["roofline"]["oracle_rays_per_frame"] = work["rays"]
+    print(json.dumps(out))
     out_arr.close()
     multi.close()
 

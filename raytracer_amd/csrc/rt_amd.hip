@@ -430,6 +430,7 @@ struct Hit {
     int a_id, b_id;
 #ifdef RT_PROFILE
     int visits;  // records visited by the wavefront (diagnostic build only)
+    unsigned long long t_end, t_leaf;  // ticks spent in CSG end records and in leaf records
 #endif
 #ifdef RT_PROFILE_MIX
     // diagnostic build: records visited by kind and how many lanes took part in each
@@ -499,6 +500,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     h.b_id = -1;
 #ifdef RT_PROFILE
     h.visits = 0;
+    h.t_end = h.t_leaf = 0;
 #endif
 #ifdef RT_PROFILE_MIX
     h.n_cull = h.a_cull = h.n_group = h.a_group = h.n_leaf = h.a_leaf = h.n_leaf_idle = 0;
@@ -721,6 +723,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (CSGM && type == T_CSG_END) {
             // CSG::local_intersect after its operands (csg.rs:150-155): sort this shape's part of
             // the list by time (stable, total order) and keep what filter_intersections keeps.
+#ifdef RT_PROFILE
+            const unsigned long long pe0 = __builtin_amdgcn_s_memtime();
+#endif
             --csg_depth;
             const int first = cl.start[csg_depth];
             const int last = cl.n < RT_MAX_CSG_HITS ? cl.n : RT_MAX_CSG_HITS;
@@ -809,6 +814,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 }
                 i = i + 1;
                 if (early && wave_ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
+#ifdef RT_PROFILE
+                h.t_end += __builtin_amdgcn_s_memtime() - pe0;
+#endif
                 continue;
             }
             for (int a = first + 1; a < last; ++a) {
@@ -866,6 +874,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             }
             i = i + 1;
             if (early && wave_ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
+#ifdef RT_PROFILE
+            h.t_end += __builtin_amdgcn_s_memtime() - pe0;
+#endif
             continue;
         }
         if (type == RT_GROUP || (CSGM && type == T_CSG_BEGIN)) {
@@ -904,6 +915,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             i = enter ? i + 1 : skip;
             continue;
         }
+#ifdef RT_PROFILE
+        const unsigned long long pl0 = __builtin_amdgcn_s_memtime();
+#endif
         V3 lo = co, ld = cd;
         if (wild) through_identity((kind >> T_LEVELS_SHIFT) & 3, lo, ld);
         if ((kind & T_DIAG) && plain) {
@@ -1039,6 +1053,9 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (early && wave_ballot(i >= skip_until) == 0ull) {
             i = wave_min(skip_until);  // INT_MAX when every lane is decided: the loop ends
         }
+#ifdef RT_PROFILE
+        h.t_leaf += __builtin_amdgcn_s_memtime() - pl0;
+#endif
     }
     __builtin_amdgcn_s_setprio(0);
     if (!TRACK) h.found = h.node >= 0;
@@ -1512,7 +1529,12 @@ DI void lane_pixel(const DevJob& J, int wave, int lane, int& px, int& row_in_til
         long long n2 = (long long)J.tile_class_count[2], n1 = (long long)J.tile_class_count[1];
         n2 = n2 < n_tiles ? n2 : n_tiles;  // the three counts add up to n_tiles; clamped so that no index below can leave its array
         n1 = n1 < n_tiles - n2 ? n1 : n_tiles - n2;
-        if (J.split > 1 && n2 * (J.split - 1) <= J.extra_blocks) split = J.split;  // else there are too many: whole tiles
+        // as many strips as the extra workgroups allow: J.split, else half of that, ..., else whole tiles
+        for (int sp = J.split; sp > 1; sp >>= 1)
+            if (n2 * (sp - 1) <= J.extra_blocks) {
+                split = sp;
+                break;
+            }
         const long long n2s = n2 * split;
         if (b < n2s) {
             strip = (int)(b % split);
@@ -1597,7 +1619,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
 #ifdef RT_PROFILE
     unsigned long long prof_t0 = __builtin_amdgcn_s_memtime();
     unsigned long long prof_closest = 0, prof_shadow = 0, prof_visits = 0, prof_traces = 0, prof_rounds = 0;
-    unsigned long long prof_prepare = 0, prof_light = 0, prof_return = 0;
+    unsigned long long prof_prepare = 0, prof_light = 0, prof_return = 0, prof_end = 0, prof_leaf = 0;
 #endif
 #ifdef RT_PROFILE_MIX
     unsigned long long mix[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1632,6 +1654,8 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
 #ifdef RT_PROFILE
         prof_closest += __builtin_amdgcn_s_memtime() - pt;
         prof_visits += h.visits;
+        prof_end += h.t_end;
+        prof_leaf += h.t_leaf;
         prof_traces += 1;
         prof_rounds += 1;
 #endif
@@ -1783,6 +1807,8 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
 #ifdef RT_PROFILE
             prof_shadow += __builtin_amdgcn_s_memtime() - ps;
             prof_visits += sh.visits;
+            prof_end += sh.t_end;
+            prof_leaf += sh.t_leaf;
             prof_traces += (wave_ballot(shadow_matters) != 0ull) ? 1 : 0;
 #endif
             if (shade) {
@@ -2133,6 +2159,8 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         atomicAdd(&counters[11], prof_prepare);
         atomicAdd(&counters[12], prof_light);
         atomicAdd(&counters[13], prof_return);
+        atomicAdd(&counters[14], prof_end);
+        atomicAdd(&counters[15], prof_leaf);
     }
 #endif
 #ifdef RT_PROFILE_MIX
@@ -3100,7 +3128,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
         // a launch of their own beside a plain launch for the other tiles was tried and is worse at
         // every size: the other tiles lose the sharing, which is most of the gain on small frames.
         int split = split_env ? split_env : (tiles >= 49152 ? 1 : (tiles >= 16384 ? 2 : 4));
-        if (split != 1 && split != 2 && split != 4) split = 1;
+        if (split != 1 && split != 2 && split != 4 && split != 8) split = 1;
         if (split > 1) {
             const long long cap = tiles / 8 > 1024 ? tiles / 8 : 1024;  // beyond that many extra strips: whole tiles
             job.split = split;
@@ -3207,8 +3235,8 @@ int fill_stats(rt_scene* s, rt_stats* st) {
 #ifdef RT_PROFILE
     {
         const unsigned long long* pc = c;
-        fprintf(stderr, "RT_PROFILE waves=%llu wave_cycles=%llu closest_cycles=%llu shadow_cycles=%llu visits=%llu traces=%llu rounds=%llu prepare_cycles=%llu lighting_cycles=%llu return_cycles=%llu\n",
-                pc[10], pc[4], pc[5], pc[6], pc[7], pc[8], pc[9], pc[11], pc[12], pc[13]);
+        fprintf(stderr, "RT_PROFILE waves=%llu wave_cycles=%llu closest_cycles=%llu shadow_cycles=%llu visits=%llu traces=%llu rounds=%llu prepare_cycles=%llu lighting_cycles=%llu return_cycles=%llu csg_end_cycles=%llu leaf_cycles=%llu\n",
+                pc[10], pc[4], pc[5], pc[6], pc[7], pc[8], pc[9], pc[11], pc[12], pc[13], pc[14], pc[15]);
     }
 #endif
     if (s->launches > 0) {

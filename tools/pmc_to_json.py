@@ -19,12 +19,14 @@ Units and corrections
     v_rcp_f64 / v_rsq_f64 4 quads) and 1.9 for the 32-bit instructions that take 2 clocks (v_mov_b32,
     v_and_b32, v_sub_f32, v_fma_f32): the counter charges at least one quad per instruction.  So
         valu_issue_frac      = 4 x SQ_ACTIVE_INST_VALU / (1024 x clocks of the launch)          (an upper bound)
-        valu_issue_frac_min  = the same with every instruction of the classes that hold 2-clock
-                               instructions (INT32, ADD/MUL/FMA_F32) charged 2 clocks instead of 4  (a lower bound)
-    and the truth lies between the two.
-  * scalar_fetch_share = SQ_INST_CYCLES_SMEM / SQ_WAVE_CYCLES: the share of the resident wavefronts' time during
-    which they have a scalar fetch in flight; 0.93-0.97 for the micro-benchmark that is nothing but a chain of
-    dependent record fetches (tools/ubench/smem_latency, same calibration file).
+        valu_issue_frac_min  = the same with 2 clocks instead of 4 for every instruction that MAY be a 2-clock
+                               one: all but the classes known to take 4 or more (the F64 classes, CVT, INT32 --
+                               which holds the carry arithmetic, not v_mov / v_and --, INT64, TRANS_F32)  (a lower bound)
+    and the truth lies between the two (compares, selects, min / max are unclassified too and take 4).
+  * SQ_INST_CYCLES_SMEM turned out to equal SQ_INSTS_SMEM (one quad per instruction, not its latency) on the
+    micro-benchmark that is nothing but a chain of dependent record fetches (tools/ubench/smem_latency), so
+    the scalar-fetch chain is priced from the walk's own counts instead (records visited per wavefront, from the
+    -DRT_PROFILE build, times the measured latency of a dependent fetch): see bench.py.
 """
 import csv
 import glob
@@ -47,18 +49,18 @@ def derive(c, e):
         e["launch_clocks"] = clocks
         e["valu_busy_quads"] = act
         e["valu_issue_frac"] = 4.0 * act / (N_SIMD * clocks)
-        fast = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_INT32", "SQ_INSTS_VALU_ADD_F32", "SQ_INSTS_VALU_MUL_F32",
-                                           "SQ_INSTS_VALU_FMA_F32"))
-        if "SQ_INSTS_VALU_INT32" in c:
+        slow = sum(c.get(k, 0.0) for k in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64",
+                                           "SQ_INSTS_VALU_TRANS_F64", "SQ_INSTS_VALU_CVT", "SQ_INSTS_VALU_INT32",
+                                           "SQ_INSTS_VALU_INT64", "SQ_INSTS_VALU_TRANS_F32"))
+        fast = c.get("SQ_INSTS_VALU", 0.0) - slow
+        if "SQ_INSTS_VALU_INT32" in c and "SQ_INSTS_VALU_ADD_F64" in c:
             e["valu_insts_in_2clock_classes"] = fast
             e["valu_issue_frac_min"] = (4.0 * act - 2.0 * fast) / (N_SIMD * clocks)
-        if c.get("SQ_INST_CYCLES_SALU"):
-            # one scalar unit per CU, shared by its four SIMDs
-            e["salu_busy_frac"] = 4.0 * c["SQ_INST_CYCLES_SALU"] / (N_SIMD / 4 * clocks)
+        if c.get("SQ_INSTS_SALU"):
+            # a SIMD gets one issue turn every four clocks and a turn takes at most one scalar instruction
+            e["salu_issue_frac"] = 4.0 * c["SQ_INSTS_SALU"] / (N_SIMD * clocks)
     if c.get("SQ_WAVE_CYCLES"):
         wc = c["SQ_WAVE_CYCLES"]
-        if c.get("SQ_INST_CYCLES_SMEM"):
-            e["scalar_fetch_share"] = c["SQ_INST_CYCLES_SMEM"] / wc
         if c.get("SQ_WAIT_ANY"):
             e["wait_any_share"] = c["SQ_WAIT_ANY"] / wc
         if c.get("SQ_WAIT_INST_ANY"):
