@@ -376,6 +376,24 @@ def e2e_block(host, torch, dev, local_rank, calls=12):
     out["rt_render_pinned_over_kernel_plus_copy"] = out["rt_render_pinned_ms"] / (kernel_ms + copy_ms)
     pinned.close()
     pinned8.close()
+    del pageable, pageable8, frame, host_pin
+    # the headline frame's way home: 7680x4320 clamped bytes to page-locked memory, per call
+    W, H = 7680, 4320
+    cam8 = scenes.default_camera(host, W, H)
+    block8 = host.camera_block(cam8)
+    big = host.pinned_empty((H, W, 3), np.uint8)
+    ptr8 = big.array.ctypes.data_as(P(ctypes.c_uint8))
+
+    def call8():
+        rc = host.abi.rt_render_u8(scene, ctypes.byref(block8), ctypes.byref(prm), ptr8, None)
+        assert rc == 0, host.abi.rt_last_error()
+    out["rt_render_u8_pinned_7680x4320_ms"] = mean_ms(call8)
+    _, k8, _, _ = timed_renders(host, world, cam8, 10, 3, torch, dev, True, local_rank)
+    out["kernel_7680x4320_u8_ms"] = k8
+    out["pinned_copy_7680x4320_u8_ms"] = W * H * 3 / (out["pinned_pcie_gbs"] * 1e9) * 1e3
+    big.close()
+    out["how"] = ("frames of 8 MB or more are rendered in five bands of tile rows (1/16, 3/16, 8/16, 3/16, 1/16) on two "
+                  "streams and every band's rows start across PCIe when the band is done (RT_BANDS=0 turns that off)")
     return out
 
 

@@ -14,7 +14,7 @@ import numpy as np
 from raytracer_amd.mirror import Api, _arr, c_d, c_dp, c_i64
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB = os.path.join(HERE, "liboracle.so")
+LIB = os.environ.get("RT_ORACLE_LIB") or os.path.join(HERE, "liboracle.so")  # RT_ORACLE_LIB: the sanitizer build
 
 COUNTER_NAMES = [
     "rays_primary", "rays_shadow", "rays_reflect", "rays_refract", "aabb_test", "sphere_test",

@@ -10,7 +10,7 @@ from . import abi
 from .mirror import Api, c_d, c_dp, c_i64
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-HOST_LIB = os.path.join(HERE, "host", "librt_host.so")
+HOST_LIB = os.environ.get("RT_HOST_LIB") or os.path.join(HERE, "host", "librt_host.so")  # RT_HOST_LIB: diagnostic builds
 
 
 class HostApi(Api):

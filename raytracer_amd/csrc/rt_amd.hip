@@ -132,6 +132,7 @@ struct DevJob {
     double inv[12];
     // partition
     int rank, world_size, tiles_x, local_tile_rows;
+    int tile_row0;    // this launch renders the rank's tile rows tile_row0 .. tile_row0 + local_tile_rows - 1 (a band of its part)
     int max_depth;
     int wide_stores;  // f64 output: base 16-byte aligned and even width; u8 output: base 4-byte aligned and width % 4 == 0
     int out_u8;       // the output is 3 bytes per pixel, quantised like Canvas::clamp, instead of 3 doubles
@@ -1421,7 +1422,7 @@ __global__ void __launch_bounds__(64) tile_class_kernel(DevScene S, DevJob J, lo
     const bool active = tile < n_tiles;
     const long long tt = active ? tile : 0;
     const int tx = (int)(tt % J.tiles_x), lty = (int)(tt / J.tiles_x);
-    int px = tx * RT_TILE + RT_TILE / 2, py = (lty * J.world_size + J.rank) * RT_TILE + RT_TILE / 2;
+    int px = tx * RT_TILE + RT_TILE / 2, py = ((lty + J.tile_row0) * J.world_size + J.rank) * RT_TILE + RT_TILE / 2;
     px = px < J.width ? px : J.width - 1;
     py = py < J.height ? py : J.height - 1;
     V3 ro, rd;
@@ -1601,7 +1602,7 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
         int px, row_in_tile, lty, rows;  // rows of the tile this wavefront renders (fewer for a strip of a class-2 tile)
         long long origin;
         lane_pixel(J, wave, lane, px, row_in_tile, lty, rows, origin);
-        const int py = (lty * J.world_size + J.rank) * RT_TILE + row_in_tile;
+        const int py = ((lty + J.tile_row0) * J.world_size + J.rank) * RT_TILE + row_in_tile;
         pending = (lane >> 3) < rows && lty < J.local_tile_rows && px < J.width && py < J.height;
         primary_ray(J, px, py, ro, rd);
     }
@@ -2334,6 +2335,10 @@ struct rt_scene {
     rtdl::Downloader dl;           // frames to caller memory (the synchronous entry points)
     bool dl_ready = false;
     hipEvent_t frame_done = nullptr;  // the staging frame is complete
+    // frames rendered in bands (render_host): two streams that take the bands in turn, one event per band
+    hipStream_t band_stream[2] = {nullptr, nullptr};
+    hipEvent_t band_done[5] = {};
+    hipEvent_t band_clear = nullptr;
 };
 
 namespace {
@@ -3074,9 +3079,21 @@ int local_tile_rows(int height, const rt_params* p) {
 // Frames with at least this many tiles are rendered expensive tiles first (see tile_class_kernel).
 constexpr long long ORDER_MIN_TILES = 4096;
 
+// One band of a frame that is rendered in several launches (render_host: band k's rows cross PCIe while
+// band k + 1 renders).  The bands of a frame share one counter set, which the caller clears before the
+// first band; every band has its own slice of the order arrays and its own tile counts per class.
+struct BandCtx {
+    long long order_offset;  // ints into the scene's order arrays
+    int slot;                // which three words after the counter shards hold this band's tiles per class
+    long long frame_tiles;   // tiles of the whole frame: what decides strips and the classifier's depth, not the band's own size
+};
+constexpr int MAX_BANDS = 16;  // COUNTER_SET_WORDS leaves 64 words after the shards: four per band
+static_assert(COUNTER_SET_WORDS - COUNTER_WORDS >= 4 * MAX_BANDS, "tile counts per class of every band");
+
 // fixed: null, or this device's static scratch (rt_render_device_static): the launch then uses the
 // counter set and the order arrays in it and allocates nothing.
-int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t stream, unsigned char* fixed = nullptr) {
+int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t stream, unsigned char* fixed = nullptr,
+           const BandCtx* band = nullptr) {
     // blocks: one per tile (or per 64 caller-supplied rays); strips of class-2 tiles are added below
     int slot = (int)(s->launches % TIMING_RING);
     // Launches on one scene must be ordered (one stream at a time): each clears the other counter set.
@@ -3085,12 +3102,18 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
     unsigned long long* other = s->d_counters + (size_t)b * COUNTER_SET_WORDS;
     int* order = s->d_order;
     const long long tiles = job.n_rays > 0 ? 0 : (long long)job.tiles_x * job.local_tile_rows;
-    if (fixed) {
+    unsigned long long* class_count = mine + COUNTER_WORDS;
+    if (band) {
+        other = nullptr;  // (the caller cleared `mine`; nothing is cleared by the kernels of a banded frame)
+        if (order) order += band->order_offset;
+        class_count += 4 * band->slot;
+    } else if (fixed) {
         // The array keeps the last call's contents: the counters (ray counts, tiles per class) must
         // start at zero; the order arrays are rewritten by the pre-pass before they are read.
         mine = reinterpret_cast<unsigned long long*>(fixed);
         other = nullptr;
         order = reinterpret_cast<int*>(fixed + STATIC_COUNTER_BYTES);
+        class_count = mine + COUNTER_WORDS;
         HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), stream));
     } else if (!s->set_clean[a]) {
         HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), stream));
@@ -3099,7 +3122,8 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
     static const bool order_enabled = !(getenv("RT_TILE_ORDER") && atoi(getenv("RT_TILE_ORDER")) == 0);
     job.tile_order = nullptr;
     if (order_enabled && s->order_useful && tiles >= ORDER_MIN_TILES) {
-        if (!fixed && tiles > s->order_cap) {
+        if (band && !order) return fail(RT_ERR_INVALID, "banded launch without order arrays");
+        if (!fixed && !band && tiles > s->order_cap) {
             if (s->d_order) HIP_TRY(hipFree(s->d_order));
             s->d_order = nullptr;
             s->order_cap = 0;
@@ -3108,7 +3132,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
             order = s->d_order;
         }
         job.tile_order = order;
-        job.tile_class_count = mine + COUNTER_WORDS;
+        job.tile_class_count = class_count;
     }
     // Tiles whose centre ray meets a transparent surface (class 2) are rendered in strips, one
     // wavefront each, so that most lanes of those wavefronts start without a pixel and take over
@@ -3127,7 +3151,8 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
         // tiles and beyond strips and sharing only add work (+13 % at 7680x4320).  Running the strips as
         // a launch of their own beside a plain launch for the other tiles was tried and is worse at
         // every size: the other tiles lose the sharing, which is most of the gain on small frames.
-        int split = split_env ? split_env : (tiles >= 49152 ? 1 : (tiles >= 16384 ? 2 : 4));
+        const long long size = band ? band->frame_tiles : tiles;
+        int split = split_env ? split_env : (size >= 49152 ? 1 : (size >= 16384 ? 2 : 4));
         if (split != 1 && split != 2 && split != 4 && split != 8) split = 1;
         if (split > 1) {
             const long long cap = tiles / 8 > 1024 ? tiles / 8 : 1024;  // beyond that many extra strips: whole tiles
@@ -3138,7 +3163,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
             share = job.split > 1;
         }
     }
-    HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
+    if (!band) HIP_TRY(hipEventRecord(s->ev_start[slot], stream));
     if (job.tile_order) {
         DevJob pre = job;
         pre.tile_order = nullptr;
@@ -3155,11 +3180,11 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
         // 90,000 tiles 0.610 / 0.580, 129,600 tiles 0.776 / 0.796, 518,400 tiles 2.886 / 2.903.
         // (The work-sharing kernel without strips gains nothing at those sizes: 0.454, 0.626, 0.789, 2.910.)
         static const int probe_env = getenv("RT_PROBE") ? atoi(getenv("RT_PROBE")) : -1;  // diagnostic
-        const int probe = probe_env >= 0 ? probe_env : ((share || (s->any_transparent && tiles < 106496)) ? 2 : 0);
+        const int probe = probe_env >= 0 ? probe_env : ((share || (s->any_transparent && (band ? band->frame_tiles : tiles) < 106496)) ? 2 : 0);
         hipLaunchKernelGGL(prek, dim3((unsigned)((tiles + 63) / 64)), dim3(64), 0, stream, s->dev, pre, tiles, probe, classes);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(tile_order_kernel, dim3((unsigned)((tiles + ORDER_BLOCK - 1) / ORDER_BLOCK)), dim3(ORDER_BLOCK), 0, stream, job.tiles_x,
-                           job.local_tile_rows, tiles, (const int*)classes, order, mine + COUNTER_WORDS);
+                           job.local_tile_rows, tiles, (const int*)classes, order, class_count);
         HIP_TRY(hipGetLastError());
     }
     if (blocks > 0) {
@@ -3188,6 +3213,7 @@ int launch(rt_scene* s, DevJob job, unsigned blocks, double* d_out, hipStream_t 
                            clears_other ? other : nullptr);
         HIP_TRY(hipGetLastError());
     }
+    if (band) return RT_OK;  // the caller does the frame's bookkeeping
     HIP_TRY(hipEventRecord(s->ev_stop[slot], stream));
     if (!fixed) {
         s->set_clean[a] = blocks == 0;
@@ -3396,6 +3422,11 @@ void rt_scene_destroy(rt_scene* s) {
     if (s->d_rays) (void)hipFree(s->d_rays);
     if (s->dl_ready) s->dl.destroy();
     if (s->frame_done) (void)hipEventDestroy(s->frame_done);
+    for (hipStream_t st : s->band_stream)
+        if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : s->band_done)
+        if (e) (void)hipEventDestroy(e);
+    if (s->band_clear) (void)hipEventDestroy(s->band_clear);
     for (int i = 0; i < TIMING_RING; ++i) {
         if (s->ev_start[i]) (void)hipEventDestroy(s->ev_start[i]);
         if (s->ev_stop[i]) (void)hipEventDestroy(s->ev_stop[i]);
@@ -3494,6 +3525,112 @@ static int ready_downloader(rt_scene* s) {
     return RT_OK;
 }
 
+// A frame on its way to HOST memory is rendered in bands of tile rows, on two streams in turn, and
+// each band's rows start across PCIe as soon as the band is done, so the copy of band k overlaps the
+// render of band k + 1.  Whichever of the two takes longer, the other is hidden except for a small
+// band at one end: the first band is small so that the copy engine starts early when the copy is the
+// longer part (an f64 frame: 3.5 ms against 0.7 ms of rendering at 3840x2160), the last band is small so
+// that little is left to copy when the render is (clamped bytes at 7680x4320: 1.8 ms against 2.6 ms).
+constexpr size_t BAND_MIN_BYTES = (size_t)8 << 20;
+constexpr int BAND_MIN_TILE_ROWS = 64;
+static const int BAND_SIXTEENTHS[5] = {1, 3, 8, 3, 1};
+static_assert(5 <= MAX_BANDS, "one slot of tile counts per band");
+
+static int render_host_banded(rt_scene* s, const rt_camera* cam, const rt_params* prm, char* out, bool out_u8,
+                              size_t row_bytes, size_t bytes) {
+    if (cam->width <= 0 || cam->height <= 0) return fail(RT_ERR_INVALID, "empty canvas");
+    for (hipStream_t& st : s->band_stream)
+        if (!st) HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (int k = 0; k < 5; ++k)
+        if (!s->band_done[k]) HIP_TRY(hipEventCreateWithFlags(&s->band_done[k], hipEventDisableTiming));
+    if (!s->band_clear) HIP_TRY(hipEventCreateWithFlags(&s->band_clear, hipEventDisableTiming));
+    DevJob job{};
+    job.width = cam->width;
+    job.height = cam->height;
+    job.half_width = cam->half_width;
+    job.half_height = cam->half_height;
+    job.pixel_size = cam->pixel_size;
+    std::memcpy(job.inv, cam->inv, sizeof job.inv);
+    job.rank = prm->rank;
+    job.world_size = prm->world_size;
+    job.tiles_x = (cam->width + RT_TILE - 1) / RT_TILE;
+    job.max_depth = prm->max_depth;
+    job.out_u8 = out_u8 ? 1 : 0;
+    const int ltr = local_tile_rows(cam->height, prm);
+    const long long frame_tiles = (long long)job.tiles_x * ltr;
+    if (frame_tiles > 0x7fffffffLL) return fail(RT_ERR_LIMIT, "frame too large for one launch");
+    // the order arrays for the whole frame, before anything is in flight (an allocation synchronises the device)
+    if (s->order_useful && frame_tiles > s->order_cap) {
+        if (s->d_order) HIP_TRY(hipFree(s->d_order));
+        s->d_order = nullptr;
+        s->order_cap = 0;
+        HIP_TRY(hipMalloc((void**)&s->d_order, 4 * (size_t)frame_tiles * sizeof(int)));
+        s->order_cap = frame_tiles;
+    }
+    const int slot = (int)(s->launches % TIMING_RING);
+    const int set = s->next_set;
+    unsigned long long* mine = s->d_counters + (size_t)set * COUNTER_SET_WORDS;
+    hipStream_t first_stream = s->band_stream[0];
+    HIP_TRY(hipEventRecord(s->ev_start[slot], first_stream));
+    HIP_TRY(hipMemsetAsync(mine, 0, COUNTER_SET_WORDS * sizeof(unsigned long long), first_stream));
+    HIP_TRY(hipEventRecord(s->band_clear, first_stream));
+    HIP_TRY(hipStreamWaitEvent(s->band_stream[1], s->band_clear, 0));
+    const bool pinned = rtdl::is_pinned(out);
+    int row0[5], rows_of[5];
+    int at = 0;
+    for (int k = 0; k < 5; ++k) {
+        int n = k == 4 ? ltr - at : (int)((long long)ltr * BAND_SIXTEENTHS[k] / 16);
+        if (n < 1) n = 1;
+        if (n > ltr - at) n = ltr - at;
+        row0[k] = at;
+        rows_of[k] = n;
+        at += n;
+    }
+    long long order_offset = 0;
+    size_t off[5], len[5];
+    for (int k = 0; k < 5; ++k) {
+        hipStream_t st = s->band_stream[k & 1];
+        off[k] = (size_t)row0[k] * RT_TILE * row_bytes;
+        len[k] = off[k] >= bytes ? 0 : std::min((size_t)rows_of[k] * RT_TILE * row_bytes, bytes - off[k]);  // the last tile row may be short
+        if (rows_of[k] > 0) {
+            job.tile_row0 = row0[k];
+            job.local_tile_rows = rows_of[k];
+            char* d_band = reinterpret_cast<char*>(s->d_frame) + off[k];
+            if (out_u8)
+                job.wide_stores = ((reinterpret_cast<uintptr_t>(d_band) & 3) == 0 && (cam->width & 3) == 0) ? 1 : 0;
+            else
+                job.wide_stores = ((reinterpret_cast<uintptr_t>(d_band) & 15) == 0 && (cam->width & 1) == 0) ? 1 : 0;
+            const long long tiles = (long long)job.tiles_x * rows_of[k];
+            BandCtx ctx{order_offset, k, frame_tiles};
+            int rc = launch(s, job, (unsigned)((tiles + RT_BLOCK_WAVES - 1) / RT_BLOCK_WAVES), reinterpret_cast<double*>(d_band), st, nullptr, &ctx);
+            if (rc != RT_OK) {
+                (void)hipDeviceSynchronize();
+                return rc;
+            }
+            order_offset += 4 * tiles;
+        }
+        HIP_TRY(hipEventRecord(s->band_done[k], st));
+        if (pinned && len[k]) HIP_TRY(s->dl.enqueue(reinterpret_cast<const char*>(s->d_frame) + off[k], len[k], out + off[k], s->band_done[k]));
+    }
+    // the frame's device time: from the first band's start to the end of the later of the last two bands
+    hipStream_t last_stream = s->band_stream[4 & 1];
+    HIP_TRY(hipStreamWaitEvent(last_stream, s->band_done[3], 0));
+    HIP_TRY(hipEventRecord(s->ev_stop[slot], last_stream));
+    s->set_clean[set] = false;
+    s->last_counters = mine;
+    s->launches++;
+    s->last_stream = last_stream;
+    if (pinned) {
+        HIP_TRY(s->dl.finish());
+    } else {
+        for (int k = 0; k < 5; ++k)
+            if (len[k])
+                HIP_TRY(s->dl.download(reinterpret_cast<const char*>(s->d_frame) + off[k], len[k], 0, 0, 1, out + off[k], s->band_done[k]));
+    }
+    HIP_TRY(hipStreamSynchronize(last_stream));
+    return RT_OK;
+}
+
 static int render_host(rt_scene* s, const rt_camera* cam, const rt_params* prm, void* out, bool out_u8,
                        rt_stats* stats) {
     if (!s || !cam) return fail(RT_ERR_INVALID, "null scene or camera");
@@ -3510,6 +3647,11 @@ static int render_host(rt_scene* s, const rt_camera* cam, const rt_params* prm, 
     HIP_TRY(hipSetDevice(s->device));
     if ((rc = reserve_frame(s, bytes)) != RT_OK) return rc;
     if ((rc = ready_downloader(s)) != RT_OK) return rc;
+    static const bool bands_enabled = !(getenv("RT_BANDS") && atoi(getenv("RT_BANDS")) == 0);  // diagnostic switch
+    if (bands_enabled && bytes >= BAND_MIN_BYTES && local_tile_rows(cam->height, prm) >= BAND_MIN_TILE_ROWS) {
+        rc = render_host_banded(s, cam, prm, static_cast<char*>(out), out_u8, row_bytes, bytes);
+        return rc != RT_OK ? rc : fill_stats(s, stats);
+    }
     rc = render_device(s, cam, prm, s->d_frame, out_u8, nullptr);
     if (rc != RT_OK) return rc;
     HIP_TRY(hipEventRecord(s->frame_done, nullptr));

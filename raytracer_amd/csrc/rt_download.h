@@ -166,6 +166,16 @@ public:
     }
     hipStream_t stream() const { return stream_; }
 
+    // Queues a copy of `n` contiguous bytes to page-locked memory behind `ready` and returns at once;
+    // finish() waits for everything queued.
+    hipError_t enqueue(const char* d_src, size_t n, char* pinned_dst, hipEvent_t ready) {
+        hipError_t e = hipSetDevice(device_);
+        if (e != hipSuccess) return e;
+        if (ready && (e = hipStreamWaitEvent(stream_, ready, 0)) != hipSuccess) return e;
+        return hipMemcpyAsync(pinned_dst, d_src, n, hipMemcpyDeviceToHost, stream_);
+    }
+    hipError_t finish() { return hipStreamSynchronize(stream_); }
+
     // Copies `total` bytes of a rank's compact buffer on the device to their places in the frame at
     // `dst` (host).  `ready`: an event after which the buffer holds the frame (may be null).
     // Returns when every byte has landed.  *staged tells which way the bytes went.

@@ -164,6 +164,28 @@ int render_to_host(rt_multi* m, const rt_camera* cam, int max_depth, void* out, 
     if (rc != RT_OK) return rc;
     if (!out) return mfail(RT_ERR_INVALID, "null output buffer");
     const double t0 = rtdl::now_ms();
+    if (m->n == 1) {
+        // One rank is the single-GPU entry point, which renders large frames in bands and sends every
+        // band home while the next one renders.
+        rt_params p{max_depth, 0, 1, 0};
+        rt_stats one{};
+        rc = u8 ? rt_render_u8(m->scene[0], cam, &p, static_cast<uint8_t*>(out), &one)
+                : rt_render(m->scene[0], cam, &p, static_cast<double*>(out), &one);
+        if (rc != RT_OK) return rc;
+        const double t_end = rtdl::now_ms();
+        if (st) {
+            std::memset(st, 0, sizeof *st);
+            st->rays_primary = one.rays_primary;
+            st->rays_shadow = one.rays_shadow;
+            st->rays_reflect = one.rays_reflect;
+            st->rays_refract = one.rays_refract;
+            st->kernel_ms = one.kernel_ms;
+            st->total_ms = (float)(t_end - t0);
+            st->render_wall_ms = one.kernel_ms < st->total_ms ? one.kernel_ms : st->total_ms;
+            st->exchange_ms = st->total_ms - st->render_wall_ms;
+        }
+        return RT_OK;
+    }
     if ((rc = launch_all(m, cam, max_depth, u8, f)) != RT_OK) return rc;
     // Every rank's tiles go home over that GPU's own PCIe link, all ranks at once.  A pinned
     // destination only needs the copies enqueued; a pageable one is filled by host threads through
