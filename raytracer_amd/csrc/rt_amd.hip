@@ -32,6 +32,7 @@
 #include <cstdlib>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rt_abi.h"
@@ -93,7 +94,7 @@ struct alignas(16) SRec {
     int type, flags, pattern, n_levels;  // n_levels: the leaf plus all its ancestors
     int anc_xf[RT_MAX_XFORM_NEST];                       // transforms of the transformed ancestors, nearest first, -1 padded
     int anc_level[RT_MAX_XFORM_NEST];                    // how many levels above the leaf each of them is
-    int tri, pad0, pad1, pad2;           // triangle normals index
+    int tri, n_anc, pad1, pad2;          // triangle normals index; how many entries of anc_xf are in use
     double inv[12];                      // the leaf's own inverse rows / transposed 3x3 (S_HAS_XFORM)
     double inv_t[9];
     double ka, kd, ks, shin, refl, transp, ri;  // Phong coefficients (phong.rs:10-19)
@@ -192,12 +193,36 @@ DI V3 xnormal(P t, V3 n) {
 // whose `ctx` link is `ctx` (Shape::intersect applied level by level, src/geometry/shape.rs:23-29,
 // and Shape::world_to_object, shape.rs:65-79).  Identity levels are exact no-ops and are skipped.
 // XF: the scene has transformed groups at all (without them no leaf has a transformed ancestor).
+// Loops over a leaf's transformed ancestors: rolled or unrolled as measured (kernel ms, csg 3840x2160 /
+// csg 1920x1080 / smooth teapot 3840x2160, all unrolled: 2.05 / 0.80 / 0.677).  The kernels for scenes with
+// transformed groups are large enough for the instruction cache to matter (1.1 % of the CSG kernel's
+// instruction fetches miss it), but a rolled loop inside the walk can also cost registers:
+//   chain_ray rolled          1.97 / 0.77 / 0.797   (only in the kernels for CSG scenes, ROLL below)
+//   to_object rolled          2.01 / 0.78 / 0.663   (kept)
+//   smooth-triangle chain     2.09 / 0.78 / 0.689   (left unrolled)
+//   normal_to_world rolled    2.06 / 0.79 / 0.669   (kept)
+#ifndef RT_ROLL_OBJ
+#define RT_ROLL_OBJ 1
+#endif
+#ifndef RT_ROLL_SMOOTH
+#define RT_ROLL_SMOOTH 0
+#endif
+#ifndef RT_ROLL_NORMAL
+#define RT_ROLL_NORMAL 1
+#endif
 template <bool XF>
 DI V3 to_object(const DevScene& S, const RT_CONST SRec* r, V3 p) {
     if (XF) {
+        // (a loop, not eight copies: the kernels for scenes with transformed groups are large enough for
+        // the instruction cache to matter)
+#if RT_ROLL_OBJ
+#pragma unroll 1
+        for (int k = r->n_anc - 1; k >= 0; --k) p = xpoint(S.xforms[r->anc_xf[k]].inv, p);
+#else
 #pragma unroll
         for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
             if (r->anc_xf[k] >= 0) p = xpoint(S.xforms[r->anc_xf[k]].inv, p);
+#endif
     }
     if (r->flags & S_HAS_XFORM) p = xpoint(r->inv, p);
     return p;
@@ -216,7 +241,26 @@ DI void through_identity(int times, V3& o, V3& d) {
 }
 // The same for a ray during traversal, on the traversal records (`ctx` is a record index there).
 // wild: see through_identity.
+template <bool ROLL>
 DI void chain_ray(const DevScene& S, int ctx, bool wild, V3& o, V3& d) {
+  if constexpr (ROLL) {
+    // The chain is found innermost first and applied outermost first.  Written as two small loops
+    // (the level-th ancestor is looked up again for every level) instead of an unrolled array of
+    // ancestors: chains are one or two levels deep in practice and this runs once per change of space.
+    int depth = 0;
+#pragma unroll 1
+    for (int c = ctx; c >= 0; c = S.trav[c].ctx) ++depth;
+#pragma unroll 1
+    for (int level = depth - 1; level >= 0; --level) {
+        int c = ctx;
+#pragma unroll 1
+        for (int up = 0; up < level; ++up) c = S.trav[c].ctx;
+        const RT_CONST double* m = S.trav[c].p;
+        if (wild) through_identity((S.trav[c].kind >> T_LEVELS_SHIFT) & 3, o, d);
+        o = xpoint(m, o);
+        d = xvec(m, d);
+    }
+  } else {
     int c[RT_MAX_XFORM_NEST];
     c[0] = ctx;
 #pragma unroll
@@ -229,6 +273,7 @@ DI void chain_ray(const DevScene& S, int ctx, bool wild, V3& o, V3& d) {
             o = xpoint(m, o);
             d = xvec(m, d);
         }
+  }
 }
 
 // BoundingBox::check_axis / Cube::check_axis (bounding_box.rs:102-124, cube.rs:47-69).
@@ -693,7 +738,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (XF && ctx != cur_ctx) {
             co = wo;
             cd = wd;
-            chain_ray(S, ctx, wild, co, cd);
+            chain_ray<CSGM>(S, ctx, wild, co, cd);
             ray_changed();
             cur_ctx = ctx;
         }
@@ -730,15 +775,26 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             --csg_depth;
             const int first = cl.start[csg_depth];
             const int last = cl.n < RT_MAX_CSG_HITS ? cl.n : RT_MAX_CSG_HITS;
-            if (wave_ballot(last - first > CSG_FAST) == 0ull) {
-                // Short lists (every lane's part has at most CSG_FAST entries: the usual case) are
-                // sorted and filtered in registers.  The list lives in scratch memory, where every
-                // step of an insertion sort is a load that depends on the one before it.
+            // (nothing collected by any lane: nothing to sort, filter or hand over)
+            if (wave_ballot(last > first) == 0ull) {
+                cl.n = first;
+                i = i + 1;
+#ifdef RT_PROFILE
+                h.t_end += __builtin_amdgcn_s_memtime() - pe0;
+#endif
+                continue;
+            }
+            // Short lists (every lane's part has at most CSG_FAST entries: the usual case) are sorted and
+            // filtered in registers, with a network for 2, 4 or 8 entries by the longest list in the wavefront.
+            // The list lives in scratch memory, where every step of an insertion sort is a load that depends
+            // on the one before it.
+            auto end_fast = [&](auto size) {
+                constexpr int N = decltype(size)::value;
                 const int m = last - first;
-                long long key[CSG_FAST];
-                int id[CSG_FAST], pos[CSG_FAST];
+                long long key[N];
+                int id[N], pos[N];
 #pragma unroll
-                for (int k = 0; k < CSG_FAST; ++k) {
+                for (int k = 0; k < N; ++k) {
                     const bool in = k < m;
                     const int at = in ? first + k : 0;
                     const double t = cl.t[at];
@@ -746,8 +802,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     key[k] = in ? total_key(t) : LLONG_MAX;
                     pos[k] = k;  // arrival order: what a stable sort keeps among equal keys
                 }
-                // 19-comparator sorting network for 8 inputs; (key, arrival) pairs are all different,
-                // so the result is the stable order.
+                // (key, arrival) pairs are all different, so the result is the stable order.
                 auto order = [&](int a, int b) {
                     const bool swap = key[b] < key[a] || (key[b] == key[a] && pos[b] < pos[a]);
                     const long long ka = key[a], kb = key[b];
@@ -759,19 +814,28 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     pos[a] = swap ? pb : pa;
                     pos[b] = swap ? pa : pb;
                 };
-                static_assert(CSG_FAST == 8, "the network below sorts eight inputs");
-                order(0, 1); order(2, 3); order(4, 5); order(6, 7);
-                order(0, 2); order(1, 3); order(4, 6); order(5, 7);
-                order(1, 2); order(5, 6); order(0, 4); order(3, 7);
-                order(1, 5); order(2, 6);
-                order(1, 4); order(3, 6);
-                order(2, 4); order(3, 5);
-                order(3, 4);
+                if constexpr (N == 2) {
+                    order(0, 1);
+                } else if constexpr (N == 4) {
+                    order(0, 1); order(2, 3);
+                    order(0, 2); order(1, 3);
+                    order(1, 2);
+                } else {
+                    static_assert(N == 8, "networks for 2, 4 and 8 inputs");
+                    // 19 comparators
+                    order(0, 1); order(2, 3); order(4, 5); order(6, 7);
+                    order(0, 2); order(1, 3); order(4, 6); order(5, 7);
+                    order(1, 2); order(5, 6); order(0, 4); order(3, 7);
+                    order(1, 5); order(2, 6);
+                    order(1, 4); order(3, 6);
+                    order(2, 4); order(3, 5);
+                    order(3, 4);
+                }
                 const int op = (kind >> T_CSG_OP_SHIFT) & 3;
                 bool inl = false, inr = false;
-                bool keep[CSG_FAST];
+                bool keep[N];
 #pragma unroll
-                for (int a = 0; a < CSG_FAST; ++a) {
+                for (int a = 0; a < N; ++a) {
                     const bool in = a < m;  // the padding sorts last
                     const bool lhit = id[a] > rnode && id[a] < skip;  // the left operand's nodes (csg.rs:91)
                     bool allowed;                                     // csg.rs:113-140
@@ -791,12 +855,12 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     for (;;) {
                         int next = INT_MAX;
 #pragma unroll
-                        for (int a = 0; a < CSG_FAST; ++a)
+                        for (int a = 0; a < N; ++a)
                             if (keep[a] && id[a] > done && id[a] < next) next = id[a];
-                        if (next == INT_MAX) break;
+                        if (wave_ballot(next != INT_MAX) == 0ull) break;
                         begin_leaf(next);
 #pragma unroll
-                        for (int a = 0; a < CSG_FAST; ++a)
+                        for (int a = 0; a < N; ++a)
                             if (keep[a] && id[a] == next) leaf_count<TRACK>(acc, key_time(key[a]));
                         commit_leaf();
                         done = next;
@@ -805,7 +869,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 } else {
                     int kept = first;
 #pragma unroll
-                    for (int a = 0; a < CSG_FAST; ++a)
+                    for (int a = 0; a < N; ++a)
                         if (keep[a]) {
                             cl.t[kept] = key_time(key[a]);
                             cl.id[kept] = id[a];
@@ -813,6 +877,22 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                         }
                     cl.n = kept;
                 }
+            };
+#ifndef RT_CSG_TIERS
+#define RT_CSG_TIERS 0
+#endif
+#if RT_CSG_TIERS
+            const unsigned long long over2 = wave_ballot(last - first > 2), over4 = wave_ballot(last - first > 4);
+#endif
+            if (wave_ballot(last - first > CSG_FAST) == 0ull) {
+#if RT_CSG_TIERS
+                if (over2 == 0ull)
+                    end_fast(std::integral_constant<int, 2>());
+                else if (over4 == 0ull)
+                    end_fast(std::integral_constant<int, 4>());
+                else
+#endif
+                    end_fast(std::integral_constant<int, CSG_FAST>());
                 i = i + 1;
                 if (early && wave_ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
 #ifdef RT_PROFILE
@@ -1093,7 +1173,11 @@ DI V3 normal_to_world(const DevScene& S, const RT_CONST SRec* r, V3 n) {
         }
         return n;
     }
+#if RT_ROLL_NORMAL
+#pragma unroll 1
+#else
 #pragma unroll
+#endif
     for (int k = 0; k <= RT_MAX_XFORM_NEST; ++k) {
         const int xf = k < RT_MAX_XFORM_NEST ? r->anc_xf[k] : -1;
         const int stop = xf >= 0 ? r->anc_level[k < RT_MAX_XFORM_NEST ? k : 0] : n_levels;
@@ -1161,6 +1245,14 @@ DI V3 normal_at(const DevScene& S, const RT_CONST SRec* sr, V3 ro, V3 rd, V3 poi
             // traversal: the same operations on the same ray give the same bits here.
             V3 lo = ro, ld = rd;
             if (XF) {
+#if RT_ROLL_SMOOTH
+#pragma unroll 1
+                for (int k = sr->n_anc - 1; k >= 0; --k) {
+                    const RT_CONST double* m = S.xforms[sr->anc_xf[k]].inv;
+                    lo = xpoint(m, lo);
+                    ld = xvec(m, ld);
+                }
+#else
 #pragma unroll
                 for (int k = RT_MAX_XFORM_NEST - 1; k >= 0; --k)
                     if (sr->anc_xf[k] >= 0) {
@@ -1168,6 +1260,7 @@ DI V3 normal_at(const DevScene& S, const RT_CONST SRec* sr, V3 ro, V3 rd, V3 poi
                         lo = xpoint(m, lo);
                         ld = xvec(m, ld);
                     }
+#endif
             }
             if (sflags & S_HAS_XFORM) {
                 lo = xpoint(sr->inv, lo);
@@ -3031,6 +3124,7 @@ std::vector<SRec> build_shade_records(const rt_scene_desc* d) {
             ++levels;
         }
         r.n_levels = levels;
+        r.n_anc = found;
         if (n.xform >= 0) {
             r.flags |= S_HAS_XFORM;
             std::memcpy(r.inv, d->xforms[n.xform].inv, sizeof r.inv);
