@@ -705,8 +705,14 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         const bool c_miss = (tmin - tmax) > G;
         bool keep = !c_miss;
         unsigned long long drop = wave_ballot(c_miss);
-        if (!CSGM || csg_depth == 0) {  // a CSG filter needs every intersection of its operands
-            if (!TRACK) {
+        // T_LINE_ONLY (a box in front of a transformed group or CSG shape with a cone below it): hits below
+        // can lie outside the box, only the ray's line decides, as in the reference's own bounds test.
+        if (!(XF && (kind & T_LINE_ONLY))) {
+            // Inside a CSG shape the filter needs every intersection up to the times that count: what lies
+            // behind the origin decides whether the ray starts inside an operand.  What lies beyond every
+            // time that counts (the light, the nearest hit so far; anything positive in the container pass)
+            // cannot change the verdict on an earlier intersection, so it may go there as well.
+            if (!TRACK && (!CSGM || csg_depth == 0)) {
                 const bool c_behind = tmax < -G;  // only positive times count
                 keep = keep && !c_behind;
                 drop |= wave_ballot(c_behind);
@@ -2794,6 +2800,7 @@ struct RecordBuilder {
     double cost_tri = 3.5;    // a triangle test,
     double cost_group = 3.5;  // a group's or CSG shape's exact bounds test
     double worth = 0.5;       // a leaf's box must have at most this share of the enclosing box's area
+    double xform_worth = 0.8; // ... and a transformed group's or CSG shape's box in front of its T_XFORM record this share
 
     const rt_scene_desc* d;
     bool no_cull;
@@ -2997,6 +3004,19 @@ struct RecordBuilder {
         // untransformed levels between this node and the space the walk keeps the ray in (see through_identity)
         int levels = 0;
         for (int a = n.parent; a >= 0 && a != n.ctx && levels < 2; a = d->nodes[a].parent) ++levels;
+        int front = -1;  // a box in the parent's space in front of this node's T_XFORM record
+        if (n.xform >= 0 && container(n) && !no_cull && box[i].ok && area(box[i].mn, box[i].mx) <= xform_worth * enclosing) {
+            // Taking the ray into a transformed group's space and back costs several box tests (33 f64
+            // operations and the single-precision set-up, twice): rays that miss the group's box in the
+            // parent's space skip that.  With a cone below, the box only tests the ray's line.
+            TRec c = r;
+            if (fill_cull(box[i].mn, box[i].mx, box[i].far, c)) {
+                if (cone_below[i]) c.kind |= T_LINE_ONLY;
+                front = (int)out.size();
+                out.push_back(c);
+                rec[i] = (int)out.size();  // what the nodes below refer to as their space is the T_XFORM record
+            }
+        }
         if (n.xform >= 0 && own_payload(n)) {
             TRec x = r;
             x.kind = T_XFORM | T_HAS_INV | (levels << T_LEVELS_SHIFT);
@@ -3065,6 +3085,7 @@ struct RecordBuilder {
         const int after = (int)out.size();
         out[at].skip = after;
         if (extra >= 0) out[extra].skip = after;
+        if (front >= 0) out[front].skip = after;
     }
 };
 
