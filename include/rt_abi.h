@@ -31,7 +31,7 @@ typedef enum rt_status {
 } rt_status;
 
 /* Limits checked by rt_scene_create / rt_render*. */
-#define RT_MAX_LIGHTS 8        /* point lights per scene */
+#define RT_MAX_LIGHTS 16       /* point lights per scene */
 #define RT_MAX_DEPTH 5         /* `remaining` of the first ray; the reference uses 5 (src/lib.rs:21) */
 #define RT_MAX_XFORM_NEST 8    /* nested groups or CSG shapes with a non-identity transform */
 #define RT_MAX_PATTERN_NEST 8  /* nested gradient/blended patterns */
@@ -39,7 +39,7 @@ typedef enum rt_status {
 #define RT_MAX_CSG_NEST 8      /* CSG shapes nested inside one another */
 #define RT_STATIC_MAX_TILES (1 << 19) /* most 8x8 tiles of one rt_render_device_static call: a 7680x4320
                                          frame has 518,400 */
-#define RT_MAX_CSG_HITS 64     /* most intersections one ray can have with an outermost CSG shape:
+#define RT_MAX_CSG_HITS 128    /* most intersections one ray can have with an outermost CSG shape:
                                   sphere, cube 2 each; cylinder, cone 4; plane, triangles 1 */
 
 /* Node kinds: the shapes of src/geometry/{group,sphere,plane,cube,cylinder,cone,triangle,

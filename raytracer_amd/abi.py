@@ -6,7 +6,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 # RT_AMD_LIB: diagnostic builds of the same library (profiling counters, tuning variants)
 LIB_PATH = os.environ.get("RT_AMD_LIB") or os.path.join(HERE, "csrc", "librt_amd.so")
 
-RT_MAX_LIGHTS = 8
+RT_MAX_LIGHTS = 16
 RT_MAX_DEPTH = 5
 RT_MAX_XFORM_NEST = 8
 RT_MAX_PATTERN_NEST = 8
@@ -15,7 +15,7 @@ RT_STATIC_MAX_TILES = 1 << 19
 RT_OK, RT_ERR_INVALID, RT_ERR_HIP, RT_ERR_LIMIT, RT_ERR_NO_DEVICE = 0, -1, -2, -3, -4
 RT_NODE_CASTS_SHADOW, RT_NODE_CLOSED = 1, 2
 RT_MAX_CSG_NEST = 8
-RT_MAX_CSG_HITS = 64
+RT_MAX_CSG_HITS = 128
 RT_NODE_CSG_DIFFERENCE, RT_NODE_CSG_INTERSECTION, RT_NODE_CSG_UNION, RT_NODE_CSG_OP_MASK = 0 << 4, 1 << 4, 2 << 4, 3 << 4
 
 c_d = C.c_double

@@ -11,14 +11,14 @@ pub const RT_ERR_HIP: c_int = -2;
 pub const RT_ERR_LIMIT: c_int = -3;
 pub const RT_ERR_NO_DEVICE: c_int = -4;
 
-pub const RT_MAX_LIGHTS: i32 = 8;
+pub const RT_MAX_LIGHTS: i32 = 16;
 pub const RT_MAX_DEPTH: i32 = 5;
 pub const RT_MAX_XFORM_NEST: i32 = 8;
 pub const RT_MAX_PATTERN_NEST: i32 = 8;
 pub const RT_TILE: i32 = 8;
 pub const RT_MAX_CSG_NEST: i32 = 8;
 pub const RT_STATIC_MAX_TILES: i32 = 1 << 19;
-pub const RT_MAX_CSG_HITS: i32 = 64;
+pub const RT_MAX_CSG_HITS: i32 = 128;
 
 // node kinds
 pub const RT_GROUP: i32 = 0;

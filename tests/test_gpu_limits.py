@@ -104,3 +104,39 @@ def test_six_nested_blended_and_gradient_patterns(host, orc):
         return api.World([floor, ball], [api.PointLight(api.point(-6, 8, -8), Color.white())])
     assert abi.RT_MAX_PATTERN_NEST >= 6
     check(host, orc, make)
+
+
+def test_twelve_lights(host, orc):
+    """Twelve lights on mirrors and glass: a suspended call keeps twelve surface colours, and the
+    reflected and refracted colours are re-added twelve times (world.rs:180-192)."""
+    def make(api):
+        M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+        floor = api.Plane(M.identity(), Phong(api.Checker(Solid(Color.white()), Solid(Color(0.2, 0.2, 0.2)), M.identity()),
+                                              0.1, 0.8, 0.1, 50.0, 0.3, 0.0, 1.0), True)
+        glass = api.Sphere(M.translation(-1.2, 1, 0), Phong(Solid(Color(0.05, 0.05, 0.1)), 0.0, 0.1, 0.9, 200.0, 0.6, 0.8, 1.5), True)
+        mirror = api.Cube(M.translation(1.4, 0.8, 0.5) * M.rotation_y(0.5) * M.scaling(0.8, 0.8, 0.8),
+                          Phong(Solid(Color(0.7, 0.3, 0.2)), 0.1, 0.6, 0.5, 80.0, 0.5, 0.0, 1.0), True)
+        lights = [api.PointLight(api.point(-9 + 1.6 * k, 5 + (k % 4), -8 + (k % 3) * 2.5), Color(0.12, 0.1 + 0.01 * k, 0.11))
+                  for k in range(12)]
+        return api.World([floor, glass, mirror], lights)
+    assert abi.RT_MAX_LIGHTS >= 12
+    check(host, orc, make, W=160, H=96)
+
+
+def test_csg_ray_with_more_than_a_hundred_intersections(host, orc):
+    """A union whose left operand is a row of 52 overlapping spheres: rays along the row meet every one of
+    them, 104 intersections (and two more with the right operand) that the shape's end sorts and filters
+    (csg.rs:80-107, 143-156).  The camera looks along the row."""
+    def make(api):
+        M, Phong, Solid, Color = api.Matrix, api.Phong, api.Solid, api.Color
+        mat = Phong(Solid(Color(0.3, 0.7, 0.4)), 0.1, 0.8, 0.5, 80.0, 0.1, 0.0, 1.0)
+        g = api.Group()
+        for k in range(52):
+            g.add_child(api.Sphere(M.translation(0.02 * math.sin(k), 1.0 + 0.02 * math.cos(1.7 * k), 0.35 * k) * M.scaling(0.5, 0.5, 0.5), mat, True))
+        cap = api.Cube(M.translation(0, 1, 19) * M.scaling(0.3, 0.3, 0.3), Phong(Solid(Color(0.8, 0.2, 0.2)), 0.1, 0.8, 0.3, 50.0, 0.0, 0.0, 1.0), True)
+        row = api.CSG(api.UNION, g, cap)
+        floor = api.Plane(M.identity(), Phong.default(), True)
+        return api.World([floor, row], [api.PointLight(api.point(-6, 8, -8), Color.white())])
+    assert abi.RT_MAX_CSG_HITS >= 106
+    check(host, orc, make, W=96, H=64, frm=(0, 1.0, -6), to=(0, 1.0, 0))
+    check(host, orc, make, W=96, H=64, frm=(2.0, 1.6, -5), to=(0, 1.0, 6))
