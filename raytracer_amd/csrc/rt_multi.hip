@@ -110,6 +110,19 @@ int frame_shape(const rt_multi* m, const rt_camera* cam, size_t pixel_bytes, Fra
     return RT_OK;
 }
 
+// The render stream, "done" event and copy stream of every rank, made on first need.
+int rank_streams(rt_multi* m) {
+    for (int r = 0; r < m->n; ++r) {
+        if (m->stream[r]) continue;
+        if (hipSetDevice(m->device[r]) != hipSuccess ||
+            hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&m->done[r], hipEventDisableTiming) != hipSuccess ||
+            m->dl[r].init(m->device[r]) != hipSuccess)
+            return mfail(RT_ERR_HIP, "stream or event creation failed");
+    }
+    return RT_OK;
+}
+
 int reserve(rt_multi* m, int r, size_t bytes) {
     if (bytes <= m->buf_bytes[r]) return RT_OK;
     MHIP(hipSetDevice(m->device[r]));
@@ -260,11 +273,13 @@ int rt_multi_create(const rt_scene_desc* desc, int32_t n_ranks, const int32_t* d
     for (int r = 0; r < n_ranks; ++r) {
         int rc = rt_scene_create(desc, m->device[r], &m->scene[r]);
         if (rc != RT_OK) return bail(rc, std::string(rt_last_error()));
-        if (hipSetDevice(m->device[r]) != hipSuccess ||
-            hipStreamCreateWithFlags(&m->stream[r], hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&m->done[r], hipEventDisableTiming) != hipSuccess ||
-            m->dl[r].init(m->device[r]) != hipSuccess)
-            return bail(RT_ERR_HIP, "stream or event creation failed");
+    }
+    // One rank renders through the single-GPU entry points, which have streams of their own: the per-rank
+    // streams are then only made if the device gather is used.  (Streams share a process's four hardware
+    // queues; every idle one more makes it likelier that a frame's copies queue up in front of its renders.)
+    if (n_ranks > 1) {
+        int rc = rank_streams(m);
+        if (rc != RT_OK) return bail(rc, std::string(rt_last_error()));
     }
     // rank 0's GPU reads its peers' buffers directly where the hardware allows it (xGMI)
     if (hipSetDevice(m->device[0]) != hipSuccess || hipEventCreate(&m->g0) != hipSuccess || hipEventCreate(&m->g1) != hipSuccess)
@@ -324,6 +339,7 @@ int rt_render_multi_device(rt_multi* m, const rt_camera* cam, int32_t max_depth,
     if (!d_frame) return mfail(RT_ERR_INVALID, "null output buffer");
     if ((f.tile_bytes & 3) != 0 || (reinterpret_cast<uintptr_t>(d_frame) & 3) != 0)
         return mfail(RT_ERR_INVALID, "rt_render_multi_device: width * bytes per pixel * 8 and the frame address must be multiples of 4");
+    if ((rc = rank_streams(m)) != RT_OK) return rc;
     const double t0 = rtdl::now_ms();
     if ((rc = launch_all(m, cam, max_depth, u8 != 0, f)) != RT_OK) return rc;
     // the exchange runs on rank 0's render stream, behind rank 0's own render
