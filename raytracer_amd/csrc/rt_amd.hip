@@ -2317,64 +2317,104 @@ __global__ void __launch_bounds__(RT_BLOCK, CSGM ? RT_MIN_WAVES_CSG : RT_MIN_WAV
 
 
 // ---------------------------------------------------------------------------------------------
-// Canvas::to_ppm (src/window/canvas.rs:62-126) on the device, from clamped bytes.  The line breaking
-// is a sequential state machine per image row (a value goes on a new line when it would make the
-// line 70 characters or more, canvas.rs:96-126) and rows are independent, so one lane formats one
-// row: a first walk measures the row's text, a scan turns lengths into offsets, a second walk
-// writes the characters.  The walks are identical so that the offsets are exact.
+// Canvas::to_ppm (src/window/canvas.rs:62-126) on the device, from clamped bytes.
+//
+// The reference's writer is a state machine per image row (canvas.rs:96-126): a value goes on a new line
+// when it would bring the line to 70 characters, a line that reaches 69 is ended at once, a row ends its
+// last line.  Two facts make it parallel.  (1) Every value is followed by exactly ONE separator, a space
+// or a newline (a line ended after its last value leaves nothing to put before the next one), so a
+// value's place in the text is the sum of (digits + 1) over the values before it, whatever the line
+// breaks are, and a row's length is that sum over the row.  (2) With c(k) the sum of (digits + 1) over
+// the values s .. k of a line that starts at value s, the line holds exactly the values with c(k) <= 70:
+// content so far + 1 + digits < 70 (canvas.rs:99) is c(k) - 1 < 70, and a line ended early at 69
+// characters (canvas.rs:118) is c(k) = 70, after which no value fits.  A line has 17 to 35 values, so one
+// wavefront finds a line's end with one prefix sum over the next 64 values, and its lanes write that
+// line's digits and separators; only the walk from line to line is sequential.  One wavefront per row.
 // ---------------------------------------------------------------------------------------------
-template <bool WRITE>
-DI unsigned ppm_row(const uint8_t* __restrict__ row, int n_values, char* __restrict__ dst) {
-    unsigned written = 0, line = 0;
-    auto put = [&](char c) {
-        if (WRITE) dst[written] = c;
-        ++written;
-    };
-    for (int i = 0; i < n_values; ++i) {
-        const unsigned v = row[i];
-        const unsigned digits = v >= 100u ? 3u : (v >= 10u ? 2u : 1u);
-        if (line + (digits + 1u) >= 70u) {
-            put('\n');
-            line = 0;
-        }
-        if (line > 0) {
-            put(' ');
-            ++line;
-        }
-        if (digits == 3u) put((char)('0' + v / 100u));
-        if (digits >= 2u) put((char)('0' + (v / 10u) % 10u));
-        put((char)('0' + v % 10u));
-        line += digits;
-        if (line + 1u == 70u) {
-            put('\n');
-            line = 0;
+constexpr int PPM_SEG = 8192;  // values of a row staged in LDS at a time (plus the 64 a line's search may look ahead)
+struct PpmHeader {
+    char text[48];  // "P3\n<width> <height>\n255\n" (canvas.rs:66-72)
+    int n;
+};
+DI unsigned ppm_cost(unsigned v) { return 2u + (v >= 10u ? 1u : 0u) + (v >= 100u ? 1u : 0u); }  // digits + separator
+__global__ void __launch_bounds__(64) ppm_measure_kernel(const uint8_t* __restrict__ rgb8, long long n_values, int height,
+                                                          unsigned long long* __restrict__ row_bytes) {
+    const int y = blockIdx.x, lane = threadIdx.x;
+    if (y >= height) return;
+    const uint8_t* __restrict__ row = rgb8 + (size_t)y * (size_t)n_values;
+    unsigned long long sum = 0;
+    for (long long k = lane; k < n_values; k += 64) sum += ppm_cost(row[k]);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+    if (lane == 0) row_bytes[y] = sum;
+}
+// row_bytes[y] becomes the offset of row y; row_bytes[height] the total.  One wavefront: every lane sums a
+// run of rows, the runs' sums are scanned across the lanes, every lane writes its run's offsets.
+__global__ void __launch_bounds__(64) ppm_scan_kernel(int height, unsigned long long first, unsigned long long* __restrict__ row_bytes) {
+    if (blockIdx.x != 0) return;
+    const int lane = threadIdx.x;
+    const int per = (height + 63) / 64;
+    const int y0 = lane * per < height ? lane * per : height, y1 = y0 + per < height ? y0 + per : height;
+    unsigned long long mine = 0;
+    for (int y = y0; y < y1; ++y) mine += row_bytes[y];
+    unsigned long long incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const unsigned long long o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    unsigned long long at = first + (incl - mine);
+    for (int y = y0; y < y1; ++y) {
+        const unsigned long long n = row_bytes[y];
+        row_bytes[y] = at;
+        at += n;
+    }
+    if (lane == 63) row_bytes[height] = first + incl;
+}
+__global__ void __launch_bounds__(64) ppm_write_kernel(const uint8_t* __restrict__ rgb8, long long n_values, int height,
+                                                        const unsigned long long* __restrict__ row_offset, unsigned long long capacity,
+                                                        PpmHeader header, char* __restrict__ text) {
+    __shared__ uint8_t win[PPM_SEG + 64];
+    const int y = blockIdx.x, lane = threadIdx.x;
+    if (y >= height || row_offset[height] > capacity) return;
+    if (y == 0 && lane < header.n) text[lane] = header.text[lane];
+    const uint8_t* __restrict__ row = rgb8 + (size_t)y * (size_t)n_values;
+    char* __restrict__ out = text + row_offset[y];
+    long long s = 0;              // first value of the current line (wave-uniform)
+    unsigned long long base = 0;  // where that value's text starts within the row's text
+    while (s < n_values) {
+        const long long seg0 = s;
+        const long long left = n_values - seg0;
+        const int n_in = (int)(left < PPM_SEG + 64 ? left : PPM_SEG + 64);
+        __builtin_amdgcn_s_waitcnt(0xc07f);  // the last line's reads of the window are done
+        __builtin_amdgcn_wave_barrier();
+        for (int k = lane; k < n_in; k += 64) win[k] = row[seg0 + k];
+        __builtin_amdgcn_s_waitcnt(0xc07f);
+        __builtin_amdgcn_wave_barrier();
+        const long long seg_end = left < PPM_SEG ? n_values : seg0 + PPM_SEG;
+        while (s < seg_end) {
+            const bool in = s + lane < n_values;  // (s - seg0 < PPM_SEG, so the window holds s .. s + 63)
+            const unsigned v = in ? win[(int)(s - seg0) + lane] : 0u;
+            const unsigned cost = in ? ppm_cost(v) : 1000u;  // nothing beyond the row's end fits a line
+            unsigned c = cost;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned o = __shfl_up(c, off, 64);
+                if (lane >= off) c += o;
+            }
+            const int fit = __builtin_popcountll(wave_ballot(c <= 70u));  // >= 1: a value alone always fits
+            if (lane < fit) {
+                char* at = out + base + (c - cost);
+                const unsigned hundreds = v / 100u, tens = (v / 10u) % 10u;
+                if (v >= 100u) *at++ = (char)('0' + hundreds);
+                if (v >= 10u) *at++ = (char)('0' + tens);
+                *at++ = (char)('0' + v % 10u);
+                *at = lane == fit - 1 ? '\n' : ' ';
+            }
+            base += (unsigned)__builtin_amdgcn_readlane((int)c, fit - 1);  // the line's length with its newline
+            s += fit;
         }
     }
-    if (line > 0) put('\n');
-    return written;
-}
-__global__ void ppm_measure_kernel(const uint8_t* __restrict__ rgb8, int width, int height, unsigned long long* __restrict__ row_bytes) {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y < height) row_bytes[y] = ppm_row<false>(rgb8 + (size_t)y * width * 3, width * 3, nullptr);
-}
-// row_bytes[y] becomes the offset of row y; row_bytes[height] the total.  A frame has a few thousand rows.
-__global__ void ppm_scan_kernel(int height, unsigned long long first, unsigned long long* __restrict__ row_bytes) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        unsigned long long at = first;
-        for (int y = 0; y < height; ++y) {
-            const unsigned long long n = row_bytes[y];
-            row_bytes[y] = at;
-            at += n;
-        }
-        row_bytes[height] = at;
-    }
-}
-__global__ void ppm_write_kernel(const uint8_t* __restrict__ rgb8, int width, int height,
-                                 const unsigned long long* __restrict__ row_offset, unsigned long long capacity,
-                                 char* __restrict__ text) {
-    const int y = blockIdx.x * blockDim.x + threadIdx.x;
-    if (y < height && row_offset[height] <= capacity)
-        ppm_row<true>(rgb8 + (size_t)y * width * 3, width * 3, text + row_offset[y]);
 }
 
 // Device self-test of rcp_exact and div_by: out_fast[i] = div_by(a[i], d[i], rcp_exact(d[i])), or NaN when
@@ -3941,18 +3981,22 @@ static int ppm_encode_device(const uint8_t* d_rgb8, int width, int height, char*
                              unsigned long long* d_work, unsigned long long* length, hipStream_t stream) {
     char header[64];
     const int hn = std::snprintf(header, sizeof header, "P3\n%d %d\n255\n", width, height);  // canvas.rs:66-72
-    const unsigned blocks = (unsigned)((height + 63) / 64);
-    hipLaunchKernelGGL(ppm_measure_kernel, dim3(blocks), dim3(64), 0, stream, d_rgb8, width, height, d_work);
+    PpmHeader head;
+    std::memset(&head, 0, sizeof head);
+    if (hn <= 0 || hn > (int)sizeof head.text) return fail(RT_ERR_INVALID, "PPM header does not fit");
+    std::memcpy(head.text, header, (size_t)hn);
+    head.n = hn;
+    const long long n_values = (long long)width * 3;
+    // one wavefront per row; the writer puts the header in front (nothing is written when the text does not fit)
+    hipLaunchKernelGGL(ppm_measure_kernel, dim3((unsigned)height), dim3(64), 0, stream, d_rgb8, n_values, height, d_work);
     hipLaunchKernelGGL(ppm_scan_kernel, dim3(1), dim3(64), 0, stream, height, (unsigned long long)hn, d_work);
-    hipLaunchKernelGGL(ppm_write_kernel, dim3(blocks), dim3(64), 0, stream, d_rgb8, width, height, d_work, capacity, d_text);
+    hipLaunchKernelGGL(ppm_write_kernel, dim3((unsigned)height), dim3(64), 0, stream, d_rgb8, n_values, height, d_work, capacity, head, d_text);
     HIP_TRY(hipGetLastError());
     unsigned long long total = 0;
     HIP_TRY(hipMemcpyAsync(&total, d_work + height, sizeof total, hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     *length = total;
     if (total > capacity) return fail(RT_ERR_LIMIT, "PPM text does not fit the buffer; *length holds the size needed");
-    HIP_TRY(hipMemcpyAsync(d_text, header, (size_t)hn, hipMemcpyHostToDevice, stream));
-    HIP_TRY(hipStreamSynchronize(stream));
     return RT_OK;
 }
 

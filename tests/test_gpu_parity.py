@@ -231,7 +231,9 @@ def test_ppm_text_on_device(host, orc):
     line2 = b"153 255 204 153 255 204 153 255 204 153 255 204 153\n"
     assert text == b"P3\n10 2\n255\n" + (line1 + line2) * 2
     rng = np.random.default_rng(2)
-    for shape in ((1, 1), (7, 23), (64, 17), (130, 5), (33, 200)):
+    # (rows of more than 8192 values are staged in several pieces on the device: 2731, 2752, 3000 and 5500
+    # pixels a row are 8193, 8256, 9000 and 16500 values)
+    for shape in ((1, 1), (7, 23), (64, 17), (130, 5), (33, 200), (2, 2731), (2, 2752), (3, 3000), (1, 5500), (70, 1)):
         for hi in (10, 100, 256):   # all 1-digit, 1-2 digits, 1-3 digits: different line breaks
             img8 = rng.integers(0, hi, size=shape + (3,), dtype=np.uint8)
             assert host.ppm_encode(img8) == host.to_ppm(img8) == orc.to_ppm(img8.astype(np.float64) / 255.0 - 1e-12 * (img8 > 0))
