@@ -151,3 +151,26 @@ def test_ragged_frame_with_cost_ordered_tiles(host, orc):
     assert img.shape == ref.shape == (H, W, 3)
     assert np.abs(img - ref).max() <= 1e-11
     assert np.array_equal(quantise(img), quantise(ref))
+
+
+def test_rows_of_a_40960x23040_frame(host, orc):
+    """Far beyond the benchmarked sizes: 943,718,400 pixels (a 22.6 GB f64 frame) as 720 ranks would share it.
+    Three of the ranks' tiles, 1.3 M pixels each, rendered here; sampled pixels against the oracle's rays
+    through the same pixels (pixel coordinates up to 40959 x 23039, pixel indices beyond 2^29)."""
+    W, H, N = 40960, 23040, 720
+    world, cam = scenes.build_world(host), scenes.default_camera(host, W, H)
+    oworld, ocam = scenes.build_world(orc), scenes.default_camera(orc, W, H)
+    rng = np.random.default_rng(5)
+    for rank in (0, 333, N - 1):
+        rows = np.asarray(host.global_rows(H, rank, N))
+        part = host.render(world, cam, rank=rank, world_size=N)
+        assert part.shape == (len(rows), W, 3) and len(rows) == 32 and np.isfinite(part).all()
+        k = rng.integers(0, len(rows), 1500)
+        x = rng.integers(0, W, 1500)
+        x[:4] = (0, W - 1, 0, W - 1)
+        k[:4] = (0, 0, len(rows) - 1, len(rows) - 1)
+        ref = sampled_reference(orc, oworld, ocam, x, rows[k])
+        got = part[k, x]
+        assert np.abs(got - ref).max() <= 1e-11
+        assert np.array_equal(quantise(got), quantise(ref))
+    assert rows[-1] == H - 1  # the last rank owns the frame's last tile
