@@ -197,7 +197,8 @@ DI V3 xnormal(P t, V3 n) {
 // csg 1920x1080 / smooth teapot 3840x2160, all unrolled: 2.05 / 0.80 / 0.677).  The kernels for scenes with
 // transformed groups are large enough for the instruction cache to matter (1.1 % of the CSG kernel's
 // instruction fetches miss it), but a rolled loop inside the walk can also cost registers:
-//   chain_ray rolled          1.97 / 0.77 / 0.797   (only in the kernels for CSG scenes, ROLL below)
+//   chain_ray rolled          1.97 / 0.77 / 0.797   (not kept: no faster any more in the kernels for CSG scenes
+//                                                   once the other loops were rolled, and see chain_ray)
 //   to_object rolled          2.01 / 0.78 / 0.663   (kept)
 //   smooth-triangle chain     2.09 / 0.78 / 0.689   (left unrolled)
 //   normal_to_world rolled    2.06 / 0.79 / 0.669   (kept)
@@ -241,26 +242,10 @@ DI void through_identity(int times, V3& o, V3& d) {
 }
 // The same for a ray during traversal, on the traversal records (`ctx` is a record index there).
 // wild: see through_identity.
-template <bool ROLL>
 DI void chain_ray(const DevScene& S, int ctx, bool wild, V3& o, V3& d) {
-  if constexpr (ROLL) {
-    // The chain is found innermost first and applied outermost first.  Written as two small loops
-    // (the level-th ancestor is looked up again for every level) instead of an unrolled array of
-    // ancestors: chains are one or two levels deep in practice and this runs once per change of space.
-    int depth = 0;
-#pragma unroll 1
-    for (int c = ctx; c >= 0; c = S.trav[c].ctx) ++depth;
-#pragma unroll 1
-    for (int level = depth - 1; level >= 0; --level) {
-        int c = ctx;
-#pragma unroll 1
-        for (int up = 0; up < level; ++up) c = S.trav[c].ctx;
-        const RT_CONST double* m = S.trav[c].p;
-        if (wild) through_identity((S.trav[c].kind >> T_LEVELS_SHIFT) & 3, o, d);
-        o = xpoint(m, o);
-        d = xvec(m, d);
-    }
-  } else {
+    // (unrolled: the rolled form, which looks the level-th ancestor up again for every level, was as fast
+    // in the kernels for CSG scenes but made the compiler keep the ray in scratch memory around it:
+    // 426 MB written per 1920x1080 csg frame against 245 MB)
     int c[RT_MAX_XFORM_NEST];
     c[0] = ctx;
 #pragma unroll
@@ -273,7 +258,6 @@ DI void chain_ray(const DevScene& S, int ctx, bool wild, V3& o, V3& d) {
             o = xpoint(m, o);
             d = xvec(m, d);
         }
-  }
 }
 
 // BoundingBox::check_axis / Cube::check_axis (bounding_box.rs:102-124, cube.rs:47-69).
@@ -435,10 +419,11 @@ struct LeafAcc {
     double negmax;
 };
 // Per-lane list of the intersections collected inside the outermost CSG shape being traversed.
+// (The list's length is a variable of its own in the walk: as a member of this struct, whose arrays are
+// indexed per lane and therefore live in scratch memory, it was loaded and stored there with every entry.)
 struct CsgList {
     double t[RT_MAX_CSG_HITS];
     int id[RT_MAX_CSG_HITS];
-    int n;
     int start[RT_MAX_CSG_NEST];  // list length when each open CSG shape began
 };
 // f64::total_cmp as an integer key (intersection.rs:60-64); the map is its own inverse.
@@ -611,7 +596,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     const bool early = (MODE == MODE_SHADOW) && S.all_cast_shadow;
     int csg_depth = 0;  // open CSG shapes around the current record (wave-uniform)
     CsgList cl;
-    cl.n = 0;
+    int cl_n = 0;  // entries in the list; counts on beyond RT_MAX_CSG_HITS, entries beyond are dropped
     LeafAcc acc;
     int acc_node = -1;
     // Intersection::hit and the container walk, one leaf at a time in depth-first order.  Stable
@@ -625,11 +610,11 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
     };
     auto leaf_add = [&](double t) {
         if (CSGM && csg_depth > 0) {
-            if (cl.n < RT_MAX_CSG_HITS) {
-                cl.t[cl.n] = t;
-                cl.id[cl.n] = acc_node;
+            if (cl_n < RT_MAX_CSG_HITS) {
+                cl.t[cl_n] = t;
+                cl.id[cl_n] = acc_node;
             }
-            ++cl.n;
+            ++cl_n;
         } else {
             leaf_count<TRACK>(acc, t);
         }
@@ -744,7 +729,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
         if (XF && ctx != cur_ctx) {
             co = wo;
             cd = wd;
-            chain_ray<CSGM>(S, ctx, wild, co, cd);
+            chain_ray(S, ctx, wild, co, cd);
             ray_changed();
             cur_ctx = ctx;
         }
@@ -780,10 +765,10 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
 #endif
             --csg_depth;
             const int first = cl.start[csg_depth];
-            const int last = cl.n < RT_MAX_CSG_HITS ? cl.n : RT_MAX_CSG_HITS;
+            const int last = cl_n < RT_MAX_CSG_HITS ? cl_n : RT_MAX_CSG_HITS;
             // (nothing collected by any lane: nothing to sort, filter or hand over)
             if (wave_ballot(last > first) == 0ull) {
-                cl.n = first;
+                cl_n = first;
                 i = i + 1;
 #ifdef RT_PROFILE
                 h.t_end += __builtin_amdgcn_s_memtime() - pe0;
@@ -871,7 +856,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                         commit_leaf();
                         done = next;
                     }
-                    cl.n = 0;
+                    cl_n = 0;
                 } else {
                     int kept = first;
 #pragma unroll
@@ -881,7 +866,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                             cl.id[kept] = id[a];
                             ++kept;
                         }
-                    cl.n = kept;
+                    cl_n = kept;
                 }
             };
 #ifndef RT_CSG_TIERS
@@ -941,23 +926,23 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 else
                     inr = !inr;
             }
-            cl.n = kept;
+            cl_n = kept;
             if (csg_depth == 0) {
                 // The survivors join the enclosing list: hand them over leaf by leaf in depth-first
                 // (= node) order, exactly as if each leaf had produced only these intersections.
                 int done = -1;
                 for (;;) {
                     int next = INT_MAX;
-                    for (int a = 0; a < cl.n; ++a)
+                    for (int a = 0; a < cl_n; ++a)
                         if (cl.id[a] > done && cl.id[a] < next) next = cl.id[a];
                     if (next == INT_MAX) break;
                     begin_leaf(next);
-                    for (int a = 0; a < cl.n; ++a)
+                    for (int a = 0; a < cl_n; ++a)
                         if (cl.id[a] == next) leaf_count<TRACK>(acc, cl.t[a]);
                     commit_leaf();
                     done = next;
                 }
-                cl.n = 0;
+                cl_n = 0;
             }
             i = i + 1;
             if (early && wave_ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
@@ -996,7 +981,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
             if (act && !inside) skip_until = skip;
             const bool enter = wave_ballot(inside) != 0ull;
             if (CSGM && type == T_CSG_BEGIN && enter) {
-                cl.start[csg_depth] = cl.n;
+                cl.start[csg_depth] = cl_n;
                 ++csg_depth;
             }
             i = enter ? i + 1 : skip;
