@@ -776,22 +776,30 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 continue;
             }
             // Short lists (every lane's part has at most CSG_FAST entries: the usual case) are sorted and
-            // filtered in registers, with a network for 2, 4 or 8 entries by the longest list in the wavefront.
-            // The list lives in scratch memory, where every step of an insertion sort is a load that depends
-            // on the one before it.
-            auto end_fast = [&](auto size) {
-                constexpr int N = decltype(size)::value;
+            // filtered in registers.  The list lives in scratch memory, where every step of an insertion sort
+            // is a load that depends on the one before it.  `bound` (2, 4 or 8, by the longest part in the
+            // wavefront) is wave-uniform: entries from there on are padding in every lane, and the loads, the
+            // comparators and the filter steps that would only touch padding are jumped over (one copy of
+            // the code: three separate networks made the kernel larger and slower).
+            auto end_fast = [&]() {
+                constexpr int N = CSG_FAST;
+                static_assert(N == 8, "the networks below are for 2, 4 and 8 inputs");
                 const int m = last - first;
+                const int bound = wave_ballot(m > 4) != 0ull ? 8 : (wave_ballot(m > 2) != 0ull ? 4 : 2);
                 long long key[N];
                 int id[N], pos[N];
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
-                    const bool in = k < m;
-                    const int at = in ? first + k : 0;
-                    const double t = cl.t[at];
-                    id[k] = cl.id[at];
-                    key[k] = in ? total_key(t) : LLONG_MAX;
+                    key[k] = LLONG_MAX;  // the padding sorts last
+                    id[k] = 0;
                     pos[k] = k;  // arrival order: what a stable sort keeps among equal keys
+                    if (k < bound) {
+                        const bool in = k < m;
+                        const int at = in ? first + k : 0;
+                        const double t = cl.t[at];
+                        id[k] = cl.id[at];
+                        key[k] = in ? total_key(t) : LLONG_MAX;
+                    }
                 }
                 // (key, arrival) pairs are all different, so the result is the stable order.
                 auto order = [&](int a, int b) {
@@ -805,14 +813,13 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     pos[a] = swap ? pb : pa;
                     pos[b] = swap ? pa : pb;
                 };
-                if constexpr (N == 2) {
+                if (bound == 2) {
                     order(0, 1);
-                } else if constexpr (N == 4) {
+                } else if (bound == 4) {
                     order(0, 1); order(2, 3);
                     order(0, 2); order(1, 3);
                     order(1, 2);
                 } else {
-                    static_assert(N == 8, "networks for 2, 4 and 8 inputs");
                     // 19 comparators
                     order(0, 1); order(2, 3); order(4, 5); order(6, 7);
                     order(0, 2); order(1, 3); order(4, 6); order(5, 7);
@@ -827,18 +834,21 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                 bool keep[N];
 #pragma unroll
                 for (int a = 0; a < N; ++a) {
-                    const bool in = a < m;  // the padding sorts last
-                    const bool lhit = id[a] > rnode && id[a] < skip;  // the left operand's nodes (csg.rs:91)
-                    bool allowed;                                     // csg.rs:113-140
-                    if (op == 0)
-                        allowed = (lhit && !inr) || (!lhit && inl);
-                    else if (op == 1)
-                        allowed = (lhit && inr) || (!lhit && inl);
-                    else
-                        allowed = (lhit && !inr) || (!lhit && !inl);
-                    keep[a] = in && allowed;
-                    inl = inl != (in && lhit);
-                    inr = inr != (in && !lhit);
+                    keep[a] = false;
+                    if (a < bound) {
+                        const bool in = a < m;  // the padding sorts last
+                        const bool lhit = id[a] > rnode && id[a] < skip;  // the left operand's nodes (csg.rs:91)
+                        bool allowed;                                     // csg.rs:113-140
+                        if (op == 0)
+                            allowed = (lhit && !inr) || (!lhit && inl);
+                        else if (op == 1)
+                            allowed = (lhit && inr) || (!lhit && inl);
+                        else
+                            allowed = (lhit && !inr) || (!lhit && !inl);
+                        keep[a] = in && allowed;
+                        inl = inl != (in && lhit);
+                        inr = inr != (in && !lhit);
+                    }
                 }
                 if (csg_depth == 0) {
                     // hand over leaf by leaf in node order, as below
@@ -847,12 +857,12 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                         int next = INT_MAX;
 #pragma unroll
                         for (int a = 0; a < N; ++a)
-                            if (keep[a] && id[a] > done && id[a] < next) next = id[a];
+                            if (a < bound && keep[a] && id[a] > done && id[a] < next) next = id[a];
                         if (wave_ballot(next != INT_MAX) == 0ull) break;
                         begin_leaf(next);
 #pragma unroll
                         for (int a = 0; a < N; ++a)
-                            if (keep[a] && id[a] == next) leaf_count<TRACK>(acc, key_time(key[a]));
+                            if (a < bound && keep[a] && id[a] == next) leaf_count<TRACK>(acc, key_time(key[a]));
                         commit_leaf();
                         done = next;
                     }
@@ -861,7 +871,7 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     int kept = first;
 #pragma unroll
                     for (int a = 0; a < N; ++a)
-                        if (keep[a]) {
+                        if (a < bound && keep[a]) {
                             cl.t[kept] = key_time(key[a]);
                             cl.id[kept] = id[a];
                             ++kept;
@@ -869,21 +879,8 @@ DI void trace(const DevScene& S, bool active, V3 wo, V3 wd, double limit, Hit& h
                     cl_n = kept;
                 }
             };
-#ifndef RT_CSG_TIERS
-#define RT_CSG_TIERS 0
-#endif
-#if RT_CSG_TIERS
-            const unsigned long long over2 = wave_ballot(last - first > 2), over4 = wave_ballot(last - first > 4);
-#endif
             if (wave_ballot(last - first > CSG_FAST) == 0ull) {
-#if RT_CSG_TIERS
-                if (over2 == 0ull)
-                    end_fast(std::integral_constant<int, 2>());
-                else if (over4 == 0ull)
-                    end_fast(std::integral_constant<int, 4>());
-                else
-#endif
-                    end_fast(std::integral_constant<int, CSG_FAST>());
+                end_fast();
                 i = i + 1;
                 if (early && wave_ballot(i >= skip_until) == 0ull) i = wave_min(skip_until);
 #ifdef RT_PROFILE
