@@ -188,8 +188,8 @@ int rt_render_device_static(rt_scene* scene, const rt_camera* camera, const rt_p
  * into rgb_out while the next slot fills. */
 int rt_render(rt_scene* scene, const rt_camera* camera, const rt_params* params, double* rgb_out,
               rt_stats* stats);
-/* render followed by Canvas::clamp on every channel (src/canvas.rs:50-60: 255*c saturated to
- * [0, 255] and rounded up, NaN -> 0): the values Canvas::to_ppm prints (src/canvas.rs:62-94),
+/* render followed by Canvas::clamp on every channel (src/window/canvas.rs:50-60: 255*c saturated to
+ * [0, 255] and rounded up, NaN -> 0): the values Canvas::to_ppm prints (src/window/canvas.rs:62-94),
  * 3 bytes per pixel in the same pixel order, without the f64 frame ever leaving the device.
  * d_rgb8 is DEVICE memory of rt_local_rows * width * 3 bytes. */
 int rt_render_device_u8(rt_scene* scene, const rt_camera* camera, const rt_params* params,
@@ -197,7 +197,7 @@ int rt_render_device_u8(rt_scene* scene, const rt_camera* camera, const rt_param
 /* Same, but synchronous into HOST memory; fills stats when not NULL. */
 int rt_render_u8(rt_scene* scene, const rt_camera* camera, const rt_params* params, uint8_t* rgb8_out,
                  rt_stats* stats);
-/* render followed by Canvas::to_ppm (src/canvas.rs:62-126), both on the device: the PPM text that
+/* render followed by Canvas::to_ppm (src/window/canvas.rs:62-126), both on the device: the PPM text that
  * main.rs writes to the output file (header, one image row per group of lines, lines broken
  * before they reach 70 characters).  text_out is HOST memory of `capacity` bytes; *length gets the
  * size of the text.  A frame needs at most 32 + height * (width * 12 + 1) bytes; when `capacity`
